@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Headline benchmark: voxel-view heatmap samples/s of the root-grid unprojection.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload root|window]
+
+Workload (BASELINE.json configs[1]): Panoptic cam5 root grid 80x80x20, batch 32
+frames, V=5 views, J=15 joints, 128x240 heatmaps, fp32, per GPU.  One step = one
+pass of the hot path over one batch: NCHW -> channel-last repack of the V
+heatmap tensors + the unprojection kernel, through the C ABI.  Inputs (heatmaps,
+packed camera table, grid axes) are resident in HBM before the timed region.
+One sample = one (voxel, view) pair producing all J channel values: B*N*V.
+
+With N > 1 ranks (launched by torch.distributed.run) every rank processes its own
+32 frames (frames x proposals partition, no data-path collective): weak scaling;
+value = samples of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='root', choices=['root', 'window'])
+    ap.add_argument('--batch', type=int, default=32, help='frames per GPU')
+    ap.add_argument('--proposals', type=int, default=10, help='window workload only')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def make_inputs(args, dev, seed):
+    """Synthetic, seeded: U[0,1) heatmaps generated on the device, ring cameras."""
+    from tempo_amd import synthetic as S
+    from tempo_amd.camera import pack_cameras
+    cfg = S.PANOPTIC
+    B, V, J = args.batch, cfg['num_views'], cfg['num_joints']
+    w, h = cfg['heatmap_size']
+    g = torch.Generator(device=dev).manual_seed(seed)
+    fms = [torch.rand(B, J, h, w, device=dev, generator=g) for _ in range(V)]
+    cams = S.ring_cameras(V, seed=seed, target=cfg['space_center'])
+    centers, scales, cameras = S.frame_meta(cams, B, cfg['raw_size'], cfg['image_size'])
+    cam = pack_cameras(centers, scales, cameras, cfg['image_size']).to(dev)
+    return cfg, fms, cam, (centers, scales, cameras)
+
+
+class RootWorkload:
+    name = 'panoptic_cam5_root_80x80x20_b32'
+
+    def __init__(self, args, dev, seed):
+        from tempo_amd import ops, project_layer as PL
+        self.ops = ops
+        self.cfg, self.fms, self.cam, _ = make_inputs(args, dev, seed)
+        cfg = self.cfg
+        self.B, self.V, self.J = args.batch, cfg['num_views'], cfg['num_joints']
+        self.axes = [(PL._base_axis(cfg['space_size'][i], cfg['cube_size'][i]) +
+                      cfg['space_center'][i]).to(dev) for i in range(3)]
+        X, Y, Z = cfg['cube_size']
+        self.N = X * Y * Z
+        w, h = cfg['heatmap_size']
+        cp = ops.padded_channels(self.J)
+        self.hm = torch.empty(self.B, self.V, h, w, cp, device=dev)
+        self.out = torch.empty(self.B, self.J, X, Y, Z, device=dev)
+        self.samples = self.B * self.N * self.V
+        # volume written once + every heatmap element read once + cameras
+        self.kernel_bytes = (4 * self.B * self.J * self.N + 4 * self.B * self.V * self.J * h * w
+                             + 128 * self.B * self.V)
+        self.kernel_name = 'unproject_kernel<ROOT>'
+
+    def repack(self):
+        self.ops.repack_nhwc(self.fms, out=self.hm)
+
+    def kernel(self):
+        self.ops.unproject_root(self.hm, self.cam, self.axes, self.J,
+                                self.cfg['heatmap_size'], self.cfg['image_size'],
+                                out=self.out)
+
+    def step(self):
+        self.repack()
+        self.kernel()
+
+
+class WindowWorkload:
+    name = 'panoptic_cam5_window_64cubed_10prop_b32'
+
+    def __init__(self, args, dev, seed):
+        from tempo_amd import ops, project_layer as PL, synthetic as S
+        self.ops = ops
+        self.cfg, self.fms, self.cam, _ = make_inputs(args, dev, seed)
+        cfg = self.cfg
+        self.B, self.V, self.J = args.batch, cfg['num_views'], cfg['num_joints']
+        P = args.proposals
+        self.NW = self.B * P
+        layer = PL.ProjectLayerWithMask(cfg['image_size'], cfg['heatmap_size'], 'mean')
+        layer.set_space_size(cfg['space_center'], cfg['space_size'], cfg['sub_space_size'],
+                             cfg['sub_cube_size'], dev)
+        props = S.make_proposals(self.NW, cfg['space_center'], cfg['space_size'], seed=seed,
+                                 invalid_every=0, margin=0.15).to(dev)
+        props[:, 5:7] = 1.0  # full windows: every voxel is sampled
+        tl, _, st, en = layer.window_geometry(props)
+        layer._ensure_grids(dev)
+        self.geo = [t.to(torch.int32).contiguous() for t in (tl, st, en)]
+        self.fine = layer._fine_axes
+        self.sub = layer._sub_cube
+        self.win_frame = (torch.arange(self.NW, device=dev, dtype=torch.int32) // P).contiguous()
+        w, h = cfg['heatmap_size']
+        cp = ops.padded_channels(self.J)
+        self.hm = torch.empty(self.B, self.V, h, w, cp, device=dev)
+        self.N = self.sub[0] * self.sub[1] * self.sub[2]
+        self.out = torch.empty(self.NW, self.J, *self.sub, device=dev)
+        self.samples = self.NW * self.N * self.V
+        self.kernel_bytes = (4 * self.NW * self.J * self.N + 4 * self.B * self.V * self.J * h * w
+                             + 128 * self.B * self.V)
+        self.kernel_name = 'unproject_kernel<WINDOW>'
+
+    def repack(self):
+        self.ops.repack_nhwc(self.fms, out=self.hm)
+
+    def kernel(self):
+        tl, st, en = self.geo
+        self.ops.unproject_window(self.hm, self.cam, self.fine, tl, st, en, self.sub, self.J,
+                                  self.cfg['heatmap_size'], self.cfg['image_size'],
+                                  win_frame=self.win_frame, out=self.out)
+
+    def step(self):
+        self.repack()
+        self.kernel()
+
+
+def cpu_baseline(args):
+    """The oracle (reference-structured torch CPU path) on BASELINE.json configs[0]:
+    Panoptic cam5, 1 frame, root grid 80x80x20 -> 640 000 samples per call."""
+    from oracle import project_layer_ref as O
+    from tempo_amd import synthetic as S
+    cfg = S.PANOPTIC
+    V, J = cfg['num_views'], cfg['num_joints']
+    w, h = cfg['heatmap_size']
+    fms = S.make_heatmaps(1, V, J, h, w, kind='noise', seed=0)
+    cams = S.ring_cameras(V, seed=0, target=cfg['space_center'])
+    centers, scales, cameras = S.frame_meta(cams, 1, cfg['raw_size'], cfg['image_size'])
+    layer = O.ProjectLayer(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    cores = min(os.cpu_count() or 1, 16)  # the GPU box grants a 16-core share
+    torch.set_num_threads(cores)
+    call = lambda: layer(fms, cfg['space_size'], [cfg['space_center']], cfg['cube_size'],
+                         centers, scales, cameras)
+    for _ in range(3):
+        call()
+    times = []
+    t_end = time.perf_counter() + 15.0
+    while len(times) < 10 or (time.perf_counter() < t_end and len(times) < 200):
+        t0 = time.perf_counter()
+        call()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    n = cfg['cube_size'][0] * cfg['cube_size'][1] * cfg['cube_size'][2]
+    return {
+        'value': round(n * V / med / 1e9, 6), 'unit': 'Gsamp/s', 'cores': cores,
+        'kind': 'port',
+        'sample': f'oracle ProjectLayer, Panoptic cam5 root 80x80x20, B=1 (640000 samples/call), '
+                  f'median of {len(times)} calls, {med * 1e3:.1f} ms/call',
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (tempo_amd has no CPU path)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    wl = (RootWorkload if args.workload == 'root' else WindowWorkload)(args, dev, seed=rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel alone, HIP events on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    rp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(args.steps)]
+    for (a, b), (c, d) in zip(ev, rp):
+        c.record()
+        wl.repack()
+        d.record()
+        a.record()
+        wl.kernel()
+        b.record()
+    torch.cuda.synchronize()
+    k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    r_ms = sum(c.elapsed_time(d) for c, d in rp) / len(rp)
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        achieved = wl.kernel_bytes / (k_ms * 1e-3) / 1e9
+        line = {
+            'metric': 'voxel-view heatmap samples/sec',
+            'value': round(wl.samples * world / (elapsed / args.steps) / 1e9, 4),
+            'unit': 'Gsamp/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(ms_step, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': wl.name, 'frames_per_gpu': args.batch, 'views': wl.V,
+                       'joints': wl.J, 'samples_per_step_per_gpu': wl.samples,
+                       'partition': f'frames x proposals over {world} rank(s), no collective'},
+            'roofline': {
+                'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                'kernel': wl.kernel_name, 'kernel_ms': round(k_ms, 4),
+                'algorithmic_bytes': wl.kernel_bytes},
+            'repack_ms': round(r_ms, 4),
+            'kernel_gsamp_s': round(wl.samples / (k_ms * 1e-3) / 1e9, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

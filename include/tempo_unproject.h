@@ -1,0 +1,129 @@
+/* tempo_unproject.h -- C ABI of the MI355X (gfx950) heatmap -> voxel unprojection.
+ *
+ * One shared library, libtempo_unproject.so, plain C symbols, no C++/torch types.
+ * The reference is 100 % Python and has no FFI of its own; each entry point
+ * below names the reference code it replaces (paths relative to the
+ * reference's root, rccchoudhury/tempo @ v1).
+ *
+ * Conventions
+ *  - every buffer is a caller-allocated DEVICE pointer (hipMalloc / torch
+ *    tensor .data_ptr()); no ownership transfer, no hidden allocation, no
+ *    host synchronisation; work is enqueued on `stream` (a hipStream_t passed
+ *    as void*, NULL = the legacy default stream);
+ *  - return value: 0 = ok, < 0 = TEMPO_E_* (bad argument, nothing launched),
+ *    > 0 = a hipError_t from the launch.  Nothing throws or exits;
+ *  - re-entrant: no mutable globals; concurrent calls on different streams
+ *    are safe as long as their output buffers do not overlap;
+ *  - all floating point is IEEE fp32; the operation order of the per-voxel
+ *    arithmetic is fixed (tempo_amd/csrc/unproject_math.h) so that results do
+ *    not depend on the launch shape.
+ *
+ * Packed camera record: 32 floats (128 B) per (frame, view):
+ *   [0..8]   R[k][j] row-major; points are row vectors: Xc = Xw @ R + T
+ *   [9..11]  T_w2c = -(T^T @ R)
+ *   [12..17] K[0][0..2], K[1][0..2]        (pixel = [x y 1] @ K^T)
+ *   [18..20] radial k0 k1 k2   [21..22] tangential p0 p1
+ *   [23]     != 0 when the distortion terms apply
+ *   [24..29] 2x3 image affine (mmpose get_affine_transform(center, scale/200, 0, image_size))
+ *   [30] width = center[0]*2   [31] height = center[1]*2
+ * (what the reference rebuilds per (batch, view) at project_layer.py:97-110 and
+ *  :240-254 through mmpose's SimpleCameraTorch / get_affine_transform.)
+ */
+#ifndef TEMPO_UNPROJECT_H
+#define TEMPO_UNPROJECT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEMPO_ABI_VERSION 1
+#define TEMPO_CAM_FLOATS 32
+#define TEMPO_MAX_VIEWS 32
+#define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
+
+enum {
+  TEMPO_OK = 0,
+  TEMPO_E_NULL = -1,      /* a required pointer is NULL */
+  TEMPO_E_DIM = -2,       /* a dimension is <= 0 or exceeds a limit above */
+  TEMPO_E_PAD = -3,       /* padded channel count not a multiple of 4 / < C */
+  TEMPO_E_SIZE = -4,      /* one view's map or one volume exceeds 2^31 bytes */
+  TEMPO_E_ARG = -5        /* any other inconsistent argument */
+};
+
+/* ABI version of the loaded library (== TEMPO_ABI_VERSION of its build). */
+int tempo_version(void);
+
+/* Static text for a return code of this library (TEMPO_E_* or hipError_t). */
+const char* tempo_error_string(int code);
+
+/* Smallest supported padded channel count for `channels` (a multiple of 4). */
+int tempo_padded_channels(int channels);
+
+/* NCHW -> channel-last repack of the V per-view heatmap tensors.
+ *   views   : HOST array of V device pointers, each fp32 [B, C_total, H, W]
+ *   c_begin : first channel to take; channels [c_begin, c_begin + C)
+ *   out     : fp32 [B, V, H, W, CP], channels C..CP-1 zero-filled
+ * Replaces nothing in the reference (it samples NCHW with F.grid_sample,
+ * project_layer.py:128-133 / :278-284); it exists so that one 16-byte fetch
+ * per lane serves four joints of one texel in the kernels below. */
+int tempo_repack_nhwc(const void* const* views, int V, int B, int C_total,
+                      int c_begin, int C, int H, int W, int CP, float* out,
+                      void* stream);
+
+/* Root-grid unprojection: ProjectLayer.get_voxel, project_layer.py:65-152
+ * (agg_method == 'mean').
+ *   hm      : [B, V, H, W, CP] from tempo_repack_nhwc
+ *   cam     : [B, V, 32] packed camera records
+ *   ax_x/y/z: voxel-centre coordinates per axis, fp32 [GB, X] / [GB, Y] / [GB, Z]
+ *             with GB = 1 (shared, ax_batched = 0) or GB = B (ax_batched = 1);
+ *             = torch.linspace(-S/2, S/2, n) + center of compute_grid(), :43-63
+ *   live    : [B] bytes, 0 = batch item skipped (volume, grids, mask stay 0),
+ *             the rule of project_layer.py:81; NULL = all live
+ *   cubes   : out fp32 [B, C, X, Y, Z]
+ *   grids   : out fp32 [B, X*Y*Z, 3] or NULL (the reference's second return)
+ *   mask    : out valid-view bitmap [B, X*Y*Z] of mask_bytes-wide words
+ *             (1, 2 or 4; bit v = view v passes the bounds test of :113-115),
+ *             or NULL with mask_bytes = 0
+ *   hm_w,hm_h / img_w,img_h : the module's heatmap_size / image_size */
+int tempo_unproject_root(const float* hm, const float* cam, const float* ax_x,
+                         const float* ax_y, const float* ax_z, int ax_batched,
+                         const uint8_t* live, float* cubes, float* grids,
+                         void* mask, int mask_bytes, int B, int V, int C,
+                         int CP, int H, int W, int X, int Y, int Z, float hm_w,
+                         float hm_h, float img_w, float img_h, void* stream);
+
+/* Per-person window unprojection: ProjectLayerWithMask.get_voxel +
+ * project_grid, project_layer.py:225-378 (agg_method == 'mean').  Only the
+ * window's own voxels are projected (the reference projects the whole fine
+ * grid and slices it, :255-276).
+ *   hm        : [F, V, H, W, CP]; cam : [F, V, 32]
+ *   win_frame : [NW] int32 frame of each window, or NULL (window i uses frame
+ *               i, NW == F: the reference's one proposal per batch item)
+ *   fx/fy/fz  : fine-grid axes over the whole space, fp32 [FX] [FY] [FZ]
+ *               (= compute_grid(space_size, space_center, fine_voxels_per_axis))
+ *   tl,start,end : int32 [NW,3]  centers_tl, start, end of :299-324
+ *   live      : [NW] bytes or NULL, the rule of :232
+ *   cubes     : out fp32 [NW, C, VX, VY, VZ]; voxels outside [start,end) are 0 */
+int tempo_unproject_window(const float* hm, const float* cam,
+                           const int32_t* win_frame, const float* fx,
+                           const float* fy, const float* fz, const int32_t* tl,
+                           const int32_t* start, const int32_t* end,
+                           const uint8_t* live, float* cubes, int NW, int F,
+                           int V, int C, int CP, int H, int W, int FX, int FY,
+                           int FZ, int VX, int VY, int VZ, float hm_w,
+                           float hm_h, float img_w, float img_h, void* stream);
+
+/* Projection only, for parity checks of the coordinate chain
+ * (SimpleCameraTorch.world_to_pixel + project_layer.py:113-126):
+ *   pts [N,3] world points, cam [M,32]  ->  pix [M,N,2] source-image pixels,
+ *   grid [M,N,2] grid_sample coordinates, inside [M,N] bytes (bounds test). */
+int tempo_project_points(const float* pts, const float* cam, int M, int N,
+                         float hm_w, float hm_h, float img_w, float img_h,
+                         float* pix, float* grid, uint8_t* inside, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEMPO_UNPROJECT_H */

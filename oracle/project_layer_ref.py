@@ -1,0 +1,400 @@
+"""CPU oracle for TEMPO's heatmap -> voxel unprojection.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this file.  The product (``tempo_amd``) never does.
+
+What it restates (all citations relative to /root/reference):
+
+* ``tempo/models/project_layer.py:43-63``   voxel-centre grid (``compute_grid``)
+* ``tempo/models/project_layer.py:65-152``  root variant  (``ProjectLayer.get_voxel``)
+* ``tempo/models/project_layer.py:184-201`` window geometry (``set_space_size``)
+* ``tempo/models/project_layer.py:225-293`` window projection (``project_grid``)
+* ``tempo/models/project_layer.py:295-378`` window variant (``ProjectLayerWithMask.get_voxel``)
+
+The reference imports four helpers from third-party packages that are absent
+from /root/reference and from this image (mmpose pinned at commit
+dd3c49418730e2d3651ff62fe04fb4319168c7c1 / 0.28.1 by ``setup.sh:9-13`` and
+``requirements.txt:77``; opencv-python 4.7.0.72 by ``requirements.txt:85``):
+
+* ``mmpose.core.camera.SimpleCameraTorch``            call sites ``project_layer.py:109-111,253-255``
+* ``mmpose...post_transforms.get_affine_transform``   call sites ``:99,:242`` (uses ``cv2.getAffineTransform``)
+* ``mmpose...post_transforms.affine_transform_torch`` call sites ``:117,:258``
+* ``mmpose.models.utils.misc.torch_meshgrid_ij``      call sites ``:55,:215``
+
+Their published algorithms are restated below.  PARITY UNPINNED: the reference
+ships no tests, golden vectors or fixtures for this path
+and the module cannot be imported here (mmcv/mmpose/cv2 missing -- an ordinary
+ModuleNotFoundError, nothing was denied), so this restatement could only be
+checked against the reference's source text, against torch's own
+``F.grid_sample`` (which it calls, exactly like the reference) and against an
+independent float64 evaluation of the same formulas (tests/test_oracle.py).
+
+The code keeps the reference's structure on purpose (python loop over batch and
+views, one ``grid_sample`` per view, the ``[B,C,1,N,V]`` intermediate, masked
+mean) because it is also the timed CPU baseline of bench.py.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------
+# third-party helpers, restated
+# --------------------------------------------------------------------------
+
+
+def meshgrid_ij(*axes):
+    """mmpose ``torch_meshgrid_ij``: ``torch.meshgrid(..., indexing='ij')``."""
+    return torch.meshgrid(*axes, indexing='ij')
+
+
+def _third_point(a, b):
+    """mmpose ``_get_3rd_point``: b + rot90(a - b), float32."""
+    d = a - b
+    return b + np.array([-d[1], d[0]], dtype=np.float32)
+
+
+def _rotate_point(pt, angle_rad):
+    sn, cs = np.sin(angle_rad), np.cos(angle_rad)
+    return [pt[0] * cs - pt[1] * sn, pt[0] * sn + pt[1] * cs]
+
+
+def _cv_get_affine_transform(src, dst):
+    """``cv2.getAffineTransform``: float32 triangles in, 2x3 float64 out.
+
+    OpenCV fills a 6x6 system (rows ``[x y 1 0 0 0]`` / ``[0 0 0 x y 1]``)
+    and solves it in double precision; so does this.
+    """
+    a = np.zeros((6, 6), dtype=np.float64)
+    b = np.zeros((6,), dtype=np.float64)
+    for i in range(3):
+        a[2 * i, 0:2] = src[i]
+        a[2 * i, 2] = 1.0
+        a[2 * i + 1, 3:5] = src[i]
+        a[2 * i + 1, 5] = 1.0
+        b[2 * i] = dst[i, 0]
+        b[2 * i + 1] = dst[i, 1]
+    return np.linalg.solve(a, b).reshape(2, 3)
+
+
+def get_affine_transform(center, scale, rot, output_size, shift=(0., 0.)):
+    """mmpose ``get_affine_transform`` (``inv=False``), 2x3 float64."""
+    assert len(center) == 2 and len(scale) == 2 and len(output_size) == 2
+    scale_tmp = scale * 200.0  # pixel_std
+    shift = np.array(shift)
+    src_w = scale_tmp[0]
+    dst_w, dst_h = output_size[0], output_size[1]
+    src_dir = _rotate_point([0., src_w * -0.5], np.pi * rot / 180)
+    dst_dir = np.array([0., dst_w * -0.5])
+
+    src = np.zeros((3, 2), dtype=np.float32)
+    src[0, :] = center + scale_tmp * shift
+    src[1, :] = center + src_dir + scale_tmp * shift
+    src[2, :] = _third_point(src[0, :], src[1, :])
+    dst = np.zeros((3, 2), dtype=np.float32)
+    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
+    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5]) + dst_dir
+    dst[2, :] = _third_point(dst[0, :], dst[1, :])
+    return _cv_get_affine_transform(np.float32(src), np.float32(dst))
+
+
+def affine_transform_torch(pts, t):
+    """mmpose ``affine_transform_torch``: ``(t @ [pts 1]^T)^T``."""
+    ones = torch.ones(pts.shape[0], 1, device=pts.device)
+    homo = torch.cat([pts, ones], dim=1)
+    out = torch.mm(t, torch.t(homo))
+    return torch.t(out[:2, :])
+
+
+class SimpleCameraTorch:
+    """mmpose ``SimpleCameraTorch`` restated (world_to_pixel path only).
+
+    ``param``: ``R`` 3x3 (camera->world), ``T`` 3x1, ``K`` 2x3 or ``f``/``c``
+    2x1 each, optional ``k`` (3) and ``p`` (2).  Row-vector convention.
+    """
+
+    def __init__(self, param, device):
+        R = torch.tensor(param['R'], device=device)
+        T = torch.tensor(param['T'], device=device)
+        assert R.shape == (3, 3) and T.shape == (3, 1)
+        self.R_w2c = R
+        self.T_w2c = -(T.T) @ R
+        if 'K' in param:
+            K = torch.tensor(param['K'], device=device)
+            assert K.shape == (2, 3)
+            self.K = K.T
+        elif 'f' in param and 'c' in param:
+            f = torch.tensor(param['f'], device=device)
+            c = torch.tensor(param['c'], device=device)
+            assert f.shape == (2, 1) and c.shape == (2, 1)
+            self.K = torch.cat([torch.diagflat(f), c], dim=-1).T
+        else:
+            raise ValueError('Camera intrinsic parameters are missing. '
+                             'Either "K" or "f"&"c" should be provided.')
+        if 'k' in param and 'p' in param:
+            self.undistortion = True
+            self.k = torch.tensor(param['k'], device=device).view(-1)
+            self.p = torch.tensor(param['p'], device=device).view(-1)
+            assert len(self.k) in {3, 6} and len(self.p) == 2
+        else:
+            self.undistortion = False
+
+    def world_to_camera(self, X):
+        return X @ self.R_w2c + self.T_w2c
+
+    def camera_to_pixel(self, X):
+        _X = X / X[..., 2:]
+        if self.undistortion:
+            k, p = self.k, self.p
+            _X_2d = _X[..., :2]
+            r2 = (_X_2d**2).sum(-1)
+            radial = 1 + sum(ki * r2**(i + 1) for i, ki in enumerate(k[:3]))
+            # (mmpose tests ``k.size == 6`` here; ``Tensor.size`` is a bound
+            # method, never equal to 6, so the rational branch is dead.)
+            tangential = 2 * (p[1] * _X[..., 0] + p[0] * _X[..., 1])
+            _X[..., :2] = _X_2d * (radial + tangential)[..., None] + torch.ger(
+                r2, p.flip([0])).reshape(_X_2d.shape)
+        return _X @ self.K
+
+    def world_to_pixel(self, X):
+        return self.camera_to_pixel(self.world_to_camera(X))
+
+
+# --------------------------------------------------------------------------
+# tempo/models/project_layer.py, restated
+# --------------------------------------------------------------------------
+
+
+def _pair(v):
+    return [v, v] if isinstance(v, int) else v
+
+
+def compute_grid(box_size, box_center, num_bins, device=None):
+    """``project_layer.py:43-63`` (and the identical copy at ``:203-223``)."""
+    if isinstance(box_size, (int, float)):
+        box_size = [box_size] * 3
+    if isinstance(num_bins, int):
+        num_bins = [num_bins] * 3
+    axes = [
+        torch.linspace(-box_size[a] / 2, box_size[a] / 2, num_bins[a],
+                       device=device) + box_center[a] for a in range(3)
+    ]
+    gx, gy, gz = meshgrid_ij(*axes)
+    return torch.cat([g.contiguous().view(-1, 1) for g in (gx, gy, gz)], dim=1)
+
+
+def _make_camera(cam_param, device):
+    if 'intrinsics' in cam_param:
+        # project_layer.py:105-107 names FisheyeCameraTorch, which is defined
+        # nowhere in the reference tree: a NameError there.
+        raise NotImplementedError('FisheyeCameraTorch is undefined in the reference')
+    return SimpleCameraTorch(param=cam_param, device=device)
+
+
+def _sample_coords(xy, trans, w, h, image_size, width, height, device):
+    """``project_layer.py:116-126`` / ``:257-268`` -- pixel -> sample grid."""
+    xy = torch.clamp(xy, -1.0, max(width, height))
+    xy = affine_transform_torch(xy, trans)
+    xy = xy * torch.tensor([w, h], dtype=torch.float, device=device) / torch.tensor(
+        image_size, dtype=torch.float, device=device)
+    g = xy / torch.tensor([w - 1, h - 1], dtype=torch.float,
+                          device=device) * 2.0 - 1.0
+    return g
+
+
+def _is_live(grid_center, i):
+    """skip rule of ``project_layer.py:81`` and ``:232``."""
+    return len(grid_center[0]) == 3 or grid_center[i][3] >= 0
+
+
+class ProjectLayer(torch.nn.Module):
+    """``project_layer.py:18-158`` (``agg_method='mean'`` only)."""
+
+    def __init__(self, image_size, heatmap_size, agg_method='mean'):
+        super().__init__()
+        if agg_method != 'mean':
+            raise NotImplementedError(agg_method)
+        self.image_size = _pair(image_size)
+        self.heatmap_size = _pair(heatmap_size)
+        self.agg_method = agg_method
+        self.last_bounding = None  # oracle extra: the valid-view mask [B,N,V]
+
+    compute_grid = staticmethod(compute_grid)
+
+    def get_voxel(self, feature_maps, grid_size, grid_center, cube_size,
+                  centers, scales, cameras):
+        device = feature_maps[0].device
+        B, C = feature_maps[0].shape[:2]
+        N = cube_size[0] * cube_size[1] * cube_size[2]
+        V = len(feature_maps)
+        cubes = torch.zeros(B, C, 1, N, V, device=device)
+        w, h = self.heatmap_size
+        grids = torch.zeros(B, N, 3, device=device)
+        bounding = torch.zeros(B, 1, 1, N, V, device=device)
+
+        for b in range(B):
+            if not _is_live(grid_center, b):
+                continue
+            gc = grid_center[0] if len(grid_center) == 1 else grid_center[b]
+            grid = compute_grid(grid_size, gc, cube_size, device=device)
+            grids[b:b + 1] = grid
+            for c in range(V):
+                center = centers[b][c]
+                scale = scales[b][c]
+                width, height = center * 2
+                trans = torch.as_tensor(
+                    get_affine_transform(center, scale / 200.0, 0, self.image_size),
+                    dtype=torch.float, device=device)
+                cam = _make_camera(cameras[b][c].copy(), device)
+                xy = cam.world_to_pixel(grid)
+                bounding[b, 0, 0, :, c] = (xy[:, 0] >= 0) & (xy[:, 1] >= 0) & (
+                    xy[:, 0] < width) & (xy[:, 1] < height)
+                g = _sample_coords(xy, trans, w, h, self.image_size, width,
+                                   height, device)
+                g = torch.clamp(g.view(1, 1, N, 2), -1.1, 1.1)
+                cubes[b:b + 1, :, :, :, c] += F.grid_sample(
+                    feature_maps[c][b:b + 1], g, align_corners=False)
+
+        self.last_bounding = bounding.view(B, N, V) > 0
+        cubes = torch.sum(torch.mul(cubes, bounding), dim=-1) / (
+            torch.sum(bounding, dim=-1) + 1e-6)
+        cubes = cubes.clamp(0.0, 1.0)
+        return cubes.view(B, C, cube_size[0], cube_size[1], cube_size[2]), grids
+
+    def forward(self, feature_maps, grid_size, grid_center, cube_size, centers,
+                scales, cameras):
+        return self.get_voxel(feature_maps, grid_size, grid_center, cube_size,
+                              centers, scales, cameras)
+
+
+class ProjectLayerWithMask(torch.nn.Module):
+    """``project_layer.py:160-388`` (``agg_method='mean'`` only)."""
+
+    def __init__(self, image_size, heatmap_size, agg_method='mean'):
+        super().__init__()
+        if agg_method != 'mean':
+            raise NotImplementedError(agg_method)
+        self.image_size = _pair(image_size)
+        self.heatmap_size = _pair(heatmap_size)
+        self.agg_method = agg_method
+        self.fine_grid = None
+        self.center_grid = None
+
+    compute_grid = staticmethod(compute_grid)
+
+    def set_space_size(self, space_center, space_size, sub_space_size,
+                       sub_cube_size, device):
+        """``project_layer.py:184-201``."""
+        self.whole_space_center = torch.tensor(space_center, device=device)
+        self.whole_space_size = torch.tensor(space_size, device=device)
+        self.ind_space_size = torch.tensor(sub_space_size, device=device)
+        self.voxels_per_axis = torch.tensor(sub_cube_size, device=device,
+                                            dtype=torch.int32)
+        self.fine_voxels_per_axis = (self.whole_space_size / self.ind_space_size *
+                                     (self.voxels_per_axis - 1)).int() + 1
+        self.scale = (self.fine_voxels_per_axis.float() - 1) / self.whole_space_size
+        self.bias = (-self.ind_space_size / 2.0 / self.whole_space_size *
+                     (self.fine_voxels_per_axis - 1) - self.scale *
+                     (self.whole_space_center - self.whole_space_size / 2.0))
+        self.num_bins = (self.voxels_per_axis[0] * self.voxels_per_axis[1] *
+                         self.voxels_per_axis[2])
+        self.num_fine_bins = (self.fine_voxels_per_axis[0] *
+                              self.fine_voxels_per_axis[1] *
+                              self.fine_voxels_per_axis[2])
+
+    def project_grid(self, feature_maps, grids, grid_center, cubes, start, end,
+                     centers_tl, centers, scales, cameras):
+        """``project_layer.py:225-293`` (raises instead of the pdb trap at :285)."""
+        B, C = feature_maps[0].shape[:2]
+        device = feature_maps[0].device
+        w, h = self.heatmap_size
+        fv = self.fine_voxels_per_axis
+        for i in range(B):
+            if not _is_live(grid_center, i):
+                continue
+            grid = self.fine_grid
+            grids[i:i + 1] = grid
+            for c in range(len(feature_maps)):
+                center = centers[i][c]
+                scale = scales[i][c]
+                width, height = center * 2
+                trans = torch.as_tensor(
+                    get_affine_transform(center, scale / 200.0, 0, self.image_size),
+                    dtype=torch.float, device=device)
+                cam = _make_camera(cameras[i][c].copy(), device)
+                xy = cam.world_to_pixel(grid)
+                g = _sample_coords(xy, trans, w, h, self.image_size, width,
+                                   height, device)
+                g = torch.clamp(g.view(1, 1, self.num_fine_bins, 2), -1.1, 1.1)
+                g = g.view(fv[0], fv[1], fv[2], 2)
+                g = g[start[i, 0]:end[i, 0], start[i, 1]:end[i, 1],
+                      start[i, 2]:end[i, 2]].reshape(1, 1, -1, 2)
+                out = F.grid_sample(feature_maps[c][i:i + 1], g,
+                                    align_corners=False).view(
+                                        C, 1, end[i, 0] - start[i, 0],
+                                        end[i, 1] - start[i, 1],
+                                        end[i, 2] - start[i, 2])
+                cubes[i, :, :,
+                      start[i, 0] - centers_tl[i, 0]:end[i, 0] - centers_tl[i, 0],
+                      start[i, 1] - centers_tl[i, 1]:end[i, 1] - centers_tl[i, 1],
+                      start[i, 2] - centers_tl[i, 2]:end[i, 2] - centers_tl[i, 2],
+                      c] += out
+        return cubes, grids
+
+    def window_geometry(self, grid_center):
+        """``project_layer.py:299-324``: centers_tl, offset, start, end."""
+        device = grid_center.device
+        B = grid_center.shape[0]
+        centers_tl = torch.round(grid_center[:, :3].float() * self.scale +
+                                 self.bias).int()
+        offset = (centers_tl.float() / (self.fine_voxels_per_axis - 1) *
+                  self.whole_space_size - self.whole_space_size / 2.0 +
+                  self.ind_space_size / 2.0)
+        mask = ((1 - grid_center[:, 5:7]) / 2 *
+                (self.voxels_per_axis[0:2] - 1)).int()
+        mask[mask < 0] = 0
+        mask = torch.cat(
+            [mask, torch.zeros((B, 1), device=device, dtype=torch.int32)], dim=1)
+        start = torch.where(centers_tl + mask >= 0, centers_tl + mask,
+                            torch.zeros_like(centers_tl))
+        end = torch.where(
+            centers_tl + self.voxels_per_axis - mask <= self.fine_voxels_per_axis,
+            centers_tl + self.voxels_per_axis - mask, self.fine_voxels_per_axis)
+        end = torch.maximum(end, start + 1)
+        return centers_tl, offset, start, end
+
+    def get_voxel(self, feature_maps, grid_center, centers, scales, cameras):
+        """``project_layer.py:295-378``."""
+        device = feature_maps[0].device
+        B, C = feature_maps[0].shape[:2]
+        V = len(feature_maps)
+        centers_tl, offset, start, end = self.window_geometry(grid_center)
+
+        if self.fine_grid is None:
+            self.fine_grid = compute_grid(self.whole_space_size,
+                                          self.whole_space_center,
+                                          self.fine_voxels_per_axis, device=device)
+            vx = self.voxels_per_axis
+            grid = compute_grid(self.ind_space_size, self.whole_space_center, vx,
+                                device=device).view(vx[0], vx[1], vx[2], 3)
+            self.center_grid = torch.stack([
+                grid[:, :, 0, :2].reshape(-1, 2), grid[:, 0, :, ::2].reshape(-1, 2),
+                grid[0, :, :, 1:].reshape(-1, 2)
+            ])
+
+        vx = self.voxels_per_axis
+        cubes = torch.zeros(B, C, 1, vx[0], vx[1], vx[2], V, device=device)
+        grids = torch.zeros(B, self.num_fine_bins, 3, device=device)
+        cubes, grids = self.project_grid(feature_maps, grids, grid_center, cubes,
+                                         start, end, centers_tl, centers, scales,
+                                         cameras)
+        bounding = torch.ones_like(cubes)
+        cubes = torch.sum(torch.mul(cubes, bounding), dim=-1) / (
+            torch.sum(bounding, dim=-1) + 1e-6)
+        cubes = cubes.clamp(0.0, 1.0)
+        return cubes.view(B, C, vx[0], vx[1], vx[2]), offset
+
+    def forward(self, feature_maps, grid_center, space_center, space_size,
+                sub_space_size, sub_cube_size, centers, scales, cameras):
+        self.set_space_size(space_center, space_size, sub_space_size,
+                            sub_cube_size, feature_maps[0].device)
+        return self.get_voxel(feature_maps, grid_center, centers, scales, cameras)

@@ -1,0 +1,8 @@
+"""tempo_amd: MI355X-native heatmap -> voxel unprojection for TEMPO.
+
+Drop-in replacements for the reference's ``tempo/models/project_layer.py``
+modules, running hand-written HIP kernels (gfx950) through a C ABI.
+"""
+from .project_layer import ProjectLayer, ProjectLayerWithMask  # noqa: F401
+
+__all__ = ['ProjectLayer', 'ProjectLayerWithMask']

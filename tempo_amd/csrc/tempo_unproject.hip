@@ -1,0 +1,482 @@
+// MI355X (gfx950) kernels + C ABI for TEMPO's heatmap -> voxel unprojection.
+//
+// Reference behaviour replaced (paths relative to the reference's root):
+//   tempo/models/project_layer.py:65-152   ProjectLayer.get_voxel        (MODE_ROOT)
+//   tempo/models/project_layer.py:225-378  ProjectLayerWithMask.get_voxel (MODE_WINDOW)
+// See include/tempo_unproject.h for the ABI and DESIGN.md for the layout and
+// the roofline reasoning.  No MFMA: the path is a gather + streaming store.
+//
+// Kernel structure (one 256-thread workgroup = one tile of TILE consecutive
+// voxels of one batch item / window):
+//   phase A  one lane per (voxel, view): project, distort, bounds-test, turn the
+//            sample point into 4 texel byte-offsets + 4 bilinear weights, park
+//            them in LDS.  The camera record is wave-uniform -> scalar loads.
+//   phase B  L lanes per voxel, lane cq owns channels 4cq..4cq+3: for every
+//            view one 16-byte buffer_load per texel (L lanes read one texel's
+//            CP*4 contiguous bytes), texels outside the map / views failing
+//            the bounds test use an out-of-range offset, which the buffer
+//            hardware answers with 0 and no memory traffic; bilinear mix and
+//            the view sum run in registers in torch's summation order.
+//   phase C  normalise, clamp, transpose through LDS, store TILE*4 contiguous
+//            bytes per channel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tempo_unproject.h"
+#include "unproject_math.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr unsigned kInvalid = 0x80000000u;  // >= any view's byte size (host-checked)
+constexpr int MODE_ROOT = 0;
+constexpr int MODE_WINDOW = 1;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct UnprojArgs {
+  const float* hm;
+  const float* cam;
+  const float* ax[3];
+  const uint8_t* live;
+  const int32_t* win_frame;
+  const int32_t* tl;
+  const int32_t* start;
+  const int32_t* end;
+  float* cubes;
+  float* grids;
+  void* mask;
+  long long ax_stride[3];  // root: floats between batch items (0 = shared axes)
+  long long frame_stride;  // floats per frame of hm = V*H*W*CP
+  unsigned view_bytes;     // H*W*CP*4
+  int NB;                  // batch items (root) / windows
+  int V, C, CP, H, W;
+  int dim[3];  // output voxels per axis
+  int fdim[3]; // window: extent of the fine axes
+  int F;       // frames in hm / cam
+  int N;       // dim[0]*dim[1]*dim[2]
+  int tiles;   // tiles per batch item
+  int total;   // NB * tiles
+  int chunk;   // ceil(total / 8): contiguous run of work items per XCD label
+  int mask_bytes;
+  int n_slots;  // view slots, padded to a multiple of VU
+  float hm_w, hm_h, img_w, img_h;
+};
+
+template <int MODE>
+__device__ __forceinline__ bool voxel_world(const UnprojArgs& a, int b, int n,
+                                            float* x, float* y, float* z) {
+  const int i2 = n % a.dim[2];
+  const int t = n / a.dim[2];
+  const int i1 = t % a.dim[1];
+  const int i0 = t / a.dim[1];
+  if (MODE == MODE_ROOT) {
+    *x = a.ax[0][b * a.ax_stride[0] + i0];
+    *y = a.ax[1][b * a.ax_stride[1] + i1];
+    *z = a.ax[2][b * a.ax_stride[2] + i2];
+    return true;
+  } else {
+    const int f0 = a.tl[3 * b + 0] + i0;
+    const int f1 = a.tl[3 * b + 1] + i1;
+    const int f2 = a.tl[3 * b + 2] + i2;
+    const bool act = f0 >= a.start[3 * b + 0] && f0 < a.end[3 * b + 0] &&
+                     f1 >= a.start[3 * b + 1] && f1 < a.end[3 * b + 1] &&
+                     f2 >= a.start[3 * b + 2] && f2 < a.end[3 * b + 2] &&
+                     (unsigned)f0 < (unsigned)a.fdim[0] &&  // never read past an axis
+                     (unsigned)f1 < (unsigned)a.fdim[1] && (unsigned)f2 < (unsigned)a.fdim[2];
+    if (!act) return false;
+    *x = a.ax[0][f0];
+    *y = a.ax[1][f1];
+    *z = a.ax[2][f2];
+    return true;
+  }
+}
+
+template <int MODE, int L, int VU>
+__global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a) {
+  constexpr int VPW = 64 / L;      // voxels per wave in phase B
+  constexpr int TILE = 4 * VPW;    // voxels per workgroup
+  constexpr int NCH = (TILE + 63) / 64;
+  constexpr int TSTR = TILE + 4;   // row stride of the output staging tile
+  extern __shared__ __align__(16) unsigned char smem[];
+  u32x4* s_off = reinterpret_cast<u32x4*>(smem);
+  float4* s_wt = reinterpret_cast<float4*>(smem + (size_t)a.n_slots * TILE * 16);
+  float* s_out = reinterpret_cast<float*>(smem);
+
+  // XCD-aware work order: workgroups b, b+8, b+16.. share an XCD (and its L2);
+  // give each such group one contiguous run of (batch item, tile) pairs so an
+  // XCD's L2 holds the heatmaps of one frame at a time.
+  const int bid = blockIdx.x;
+  const int run = bid >> 3;
+  const int item = (bid & 7) * a.chunk + run;
+  if (run >= a.chunk || item >= a.total) return;
+  const int b = item / a.tiles;
+  const int n0 = (item - b * a.tiles) * TILE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int CPB = a.CP * 4;
+
+  int frame = b;
+  if (MODE == MODE_WINDOW && a.win_frame != nullptr) frame = a.win_frame[b];
+  const bool dead = (a.live != nullptr && a.live[b] == 0) || (unsigned)frame >= (unsigned)a.F;
+  if (dead) {
+    for (int i = tid; i < a.C * TILE; i += kThreads) {
+      const int ch = i / TILE, n = n0 + (i - ch * TILE);
+      if (n < a.N) a.cubes[((long long)b * a.C + ch) * a.N + n] = 0.0f;
+    }
+    for (int i = tid; i < TILE; i += kThreads) {
+      const int n = n0 + i;
+      if (n >= a.N) continue;
+      if (a.grids != nullptr) {
+        float* g = a.grids + ((long long)b * a.N + n) * 3;
+        g[0] = g[1] = g[2] = 0.0f;
+      }
+      if (a.mask != nullptr) {
+        uint8_t* m = (uint8_t*)a.mask + ((long long)b * a.N + n) * a.mask_bytes;
+        for (int k = 0; k < a.mask_bytes; k++) m[k] = 0;
+      }
+    }
+    return;
+  }
+
+  // ---------------------------------------------------------------- phase A
+  for (int wi = wave; wi < a.n_slots * NCH; wi += 4) {
+    const int slot = wi / NCH;
+    const int vox = (wi - slot * NCH) * 64 + lane;
+    const int view = tempo_view_of_slot(slot, a.V);
+    if (vox >= TILE) continue;
+    u32x4 off = {kInvalid, kInvalid, kInvalid, kInvalid};
+    float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n = n0 + vox;
+    float x, y, z;
+    if (view >= 0 && n < a.N && voxel_world<MODE>(a, b, n, &x, &y, &z)) {
+      const float* cam = a.cam + ((long long)frame * a.V + view) * CAM_FLOATS;
+      const TempoPix p = tempo_world_to_pixel(cam, x, y, z);
+      float gx, gy;
+      tempo_pixel_to_grid(cam, p.px, p.py, a.hm_w, a.hm_h, a.img_w, a.img_h, &gx, &gy);
+      const TempoTap t = tempo_bilinear_tap(gx, gy, a.W, a.H);
+      // root: a view that fails the bounds test is multiplied by 0 in the
+      // reference; skip its texels unless the coordinates are NaN (then the
+      // reference's 0 * NaN poisons the voxel and so must we).
+      const bool skip = (MODE == MODE_ROOT) && !p.inside && gx == gx && gy == gy;
+      const bool x0ok = (unsigned)t.x0 < (unsigned)a.W;
+      const bool x1ok = (unsigned)(t.x0 + 1) < (unsigned)a.W;
+      const bool y0ok = (unsigned)t.y0 < (unsigned)a.H;
+      const bool y1ok = (unsigned)(t.y0 + 1) < (unsigned)a.H;
+      const unsigned base = (unsigned)((t.y0 * a.W + t.x0) * CPB);
+      const unsigned row = (unsigned)(a.W * CPB);
+      if (!skip) {
+        off.x = (x0ok && y0ok) ? base : kInvalid;
+        off.y = (x1ok && y0ok) ? base + CPB : kInvalid;
+        off.z = (x0ok && y1ok) ? base + row : kInvalid;
+        off.w = (x1ok && y1ok) ? base + row + CPB : kInvalid;
+      }
+      if (MODE == MODE_ROOT) off.x |= (unsigned)p.inside;  // bit 0 rides along
+      wt = make_float4(t.nw, t.ne, t.sw, t.se);
+    }
+    s_off[slot * TILE + vox] = off;
+    s_wt[slot * TILE + vox] = wt;
+  }
+  if (MODE == MODE_ROOT && a.grids != nullptr) {
+    for (int i = tid; i < TILE; i += kThreads) {
+      const int n = n0 + i;
+      float x, y, z;
+      if (n < a.N && voxel_world<MODE>(a, b, n, &x, &y, &z)) {
+        float* g = a.grids + ((long long)b * a.N + n) * 3;
+        g[0] = x;
+        g[1] = y;
+        g[2] = z;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- phase B
+  const bool lane_on = lane < VPW * L;
+  const int vq = lane / L;
+  const int cq = lane - vq * L;
+  const int vsl = lane_on ? wave * VPW + vq : 0;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int cnt = 0;
+  unsigned mbits = 0;
+  const char* fbase = reinterpret_cast<const char*>(a.hm + (long long)frame * a.frame_stride);
+  for (int s0 = 0; s0 < a.n_slots; s0 += VU) {
+    u32x4 o[VU];
+    float4 w[VU];
+    u32x4 tex[VU][4];
+#pragma unroll
+    for (int u = 0; u < VU; u++) {
+      o[u] = s_off[(s0 + u) * TILE + vsl];
+      w[u] = s_wt[(s0 + u) * TILE + vsl];
+    }
+#pragma unroll
+    for (int u = 0; u < VU; u++) {
+      const int view = tempo_view_of_slot(s0 + u, a.V);
+      const char* vbase = fbase + (long long)(view < 0 ? 0 : view) * a.view_bytes;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(vbase), 0, (int)a.view_bytes, 0x00020000);
+      const unsigned lo = (unsigned)cq * 16u;
+      tex[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (o[u].x & ~15u) + lo, 0, 0);
+      tex[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].y + lo, 0, 0);
+      tex[u][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].z + lo, 0, 0);
+      tex[u][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].w + lo, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < VU; u++) {
+      const int view = tempo_view_of_slot(s0 + u, a.V);
+      const unsigned in = o[u].x & 1u;
+      cnt += (int)in;
+      if (view >= 0) mbits |= in << view;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const float s = tempo_bilinear_mix(
+            __uint_as_float(tex[u][0][c]), __uint_as_float(tex[u][1][c]),
+            __uint_as_float(tex[u][2][c]), __uint_as_float(tex[u][3][c]), w[u].x,
+            w[u].y, w[u].z, w[u].w);
+        acc[c] = acc[c] + s;
+      }
+    }
+  }
+  __syncthreads();  // every wave is done reading s_off / s_wt; s_out aliases them
+
+  // ---------------------------------------------------------------- phase C
+  const float den = (MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f;
+  if (lane_on) {
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+      s_out[(4 * cq + c) * TSTR + vsl] = tempo_nan_clamp(acc[c] / den, 0.0f, 1.0f);
+    if (MODE == MODE_ROOT && a.mask != nullptr && cq == 0 && n0 + vsl < a.N) {
+      char* m = (char*)a.mask + ((long long)b * a.N + n0 + vsl) * a.mask_bytes;
+      if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mbits;
+      else if (a.mask_bytes == 2) *(uint16_t*)m = (uint16_t)mbits;
+      else *(uint32_t*)m = mbits;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < a.C * TILE; i += kThreads) {
+    const int ch = i / TILE, vox = i - ch * TILE;
+    const int n = n0 + vox;
+    if (n < a.N) a.cubes[((long long)b * a.C + ch) * a.N + n] = s_out[ch * TSTR + vox];
+  }
+}
+
+// ------------------------------------------------------------------ repack
+struct RepackArgs {
+  const float* views[TEMPO_MAX_VIEWS];
+  float* out;
+  int V, B, C_total, c_begin, C, HW, CP;
+};
+
+constexpr int kRepackPix = 64;
+
+__global__ __launch_bounds__(kThreads) void repack_kernel(const RepackArgs a) {
+  __shared__ float s[TEMPO_MAX_CHANNELS][kRepackPix + 1];
+  const int p0 = blockIdx.x * kRepackPix;
+  const int v = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* in = a.views[v] + ((long long)b * a.C_total + a.c_begin) * a.HW;
+  for (int c = wave; c < a.CP; c += 4) {
+    float val = 0.0f;
+    if (c < a.C && p0 + lane < a.HW) val = in[(long long)c * a.HW + p0 + lane];
+    s[c][lane] = val;
+  }
+  __syncthreads();
+  const int L = a.CP >> 2;
+  float4* out = reinterpret_cast<float4*>(
+      a.out + (((long long)b * a.V + v) * a.HW + p0) * a.CP);
+  for (int i = tid; i < kRepackPix * L; i += kThreads) {
+    const int p = i / L, cq = i - p * L;
+    if (p0 + p < a.HW)
+      out[i] = make_float4(s[4 * cq][p], s[4 * cq + 1][p], s[4 * cq + 2][p],
+                           s[4 * cq + 3][p]);
+  }
+}
+
+// ---------------------------------------------------------- project points
+__global__ __launch_bounds__(kThreads) void project_points_kernel(
+    const float* __restrict__ pts, const float* __restrict__ cam, int N, float hm_w,
+    float hm_h, float img_w, float img_h, float* __restrict__ pix,
+    float* __restrict__ grid, uint8_t* __restrict__ inside) {
+  const int m = blockIdx.y;
+  const int n = blockIdx.x * kThreads + threadIdx.x;
+  if (n >= N) return;
+  const float* c = cam + (long long)m * CAM_FLOATS;
+  const TempoPix p = tempo_world_to_pixel(c, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2]);
+  float gx, gy;
+  tempo_pixel_to_grid(c, p.px, p.py, hm_w, hm_h, img_w, img_h, &gx, &gy);
+  const long long o = (long long)m * N + n;
+  pix[2 * o] = p.px;
+  pix[2 * o + 1] = p.py;
+  grid[2 * o] = gx;
+  grid[2 * o + 1] = gy;
+  inside[o] = (uint8_t)p.inside;
+}
+
+// ------------------------------------------------------------ host helpers
+template <int MODE, int L, int VU>
+int launch_one(const UnprojArgs& a, hipStream_t stream) {
+  constexpr int TILE = 4 * (64 / L);
+  UnprojArgs k = a;
+  k.tiles = (a.N + TILE - 1) / TILE;
+  const long long total = (long long)a.NB * k.tiles;
+  if (total > 0x7fffffffLL / 8) return TEMPO_E_DIM;
+  k.total = (int)total;
+  k.chunk = (k.total + 7) / 8;
+  k.n_slots = ((a.V + VU - 1) / VU) * VU;
+  size_t lds = (size_t)k.n_slots * TILE * 32;
+  const size_t lds_out = (size_t)a.CP * (TILE + 4) * 4;
+  if (lds_out > lds) lds = lds_out;
+  if (lds > 64 * 1024) return TEMPO_E_DIM;
+  hipLaunchKernelGGL((unproject_kernel<MODE, L, VU>), dim3(8 * k.chunk), dim3(kThreads),
+                     lds, stream, k);
+  return (int)hipGetLastError();
+}
+
+template <int MODE, int L>
+int launch_vu(const UnprojArgs& a, hipStream_t stream) {
+  // views are gathered VU at a time; pick the unroll that pads V least
+  const int pad5 = (5 - a.V % 5) % 5, pad4 = (4 - a.V % 4) % 4;
+  if (pad5 <= pad4) return launch_one<MODE, L, 5>(a, stream);
+  return launch_one<MODE, L, 4>(a, stream);
+}
+
+template <int MODE>
+int launch_mode(const UnprojArgs& a, hipStream_t stream) {
+  switch (a.CP / 4) {
+    case 4: return launch_vu<MODE, 4>(a, stream);
+    case 5: return launch_vu<MODE, 5>(a, stream);
+    case 6: return launch_vu<MODE, 6>(a, stream);
+    case 7: return launch_vu<MODE, 7>(a, stream);
+    case 8: return launch_vu<MODE, 8>(a, stream);
+    default: return TEMPO_E_PAD;
+  }
+}
+
+int check_common(int V, int C, int CP, int H, int W) {
+  if (V <= 0 || V > TEMPO_MAX_VIEWS || C <= 0 || C > TEMPO_MAX_CHANNELS || H <= 0 ||
+      W <= 0)
+    return TEMPO_E_DIM;
+  if (CP % 4 != 0 || CP < C || CP < 16 || CP > TEMPO_MAX_CHANNELS) return TEMPO_E_PAD;
+  if ((long long)H * W * CP * 4 >= 0x80000000LL) return TEMPO_E_SIZE;
+  return TEMPO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tempo_version(void) { return TEMPO_ABI_VERSION; }
+
+const char* tempo_error_string(int code) {
+  switch (code) {
+    case TEMPO_OK: return "ok";
+    case TEMPO_E_NULL: return "tempo: a required pointer is NULL";
+    case TEMPO_E_DIM: return "tempo: a dimension is <= 0 or exceeds the library limit";
+    case TEMPO_E_PAD: return "tempo: padded channel count must be a multiple of 4 in [max(C,16), 32]";
+    case TEMPO_E_SIZE: return "tempo: one view's map or one volume exceeds 2^31 bytes";
+    case TEMPO_E_ARG: return "tempo: inconsistent argument";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "tempo: unknown error";
+  }
+}
+
+int tempo_padded_channels(int channels) {
+  if (channels <= 0 || channels > TEMPO_MAX_CHANNELS) return TEMPO_E_DIM;
+  const int cp = (channels + 3) / 4 * 4;
+  return cp < 16 ? 16 : cp;
+}
+
+int tempo_repack_nhwc(const void* const* views, int V, int B, int C_total, int c_begin,
+                      int C, int H, int W, int CP, float* out, void* stream) {
+  if (views == nullptr || out == nullptr) return TEMPO_E_NULL;
+  const int rc = check_common(V, C, CP, H, W);
+  if (rc != TEMPO_OK) return rc;
+  if (B <= 0 || B > 65535 || c_begin < 0 || c_begin + C > C_total) return TEMPO_E_DIM;
+  RepackArgs a;
+  for (int v = 0; v < V; v++) {
+    if (views[v] == nullptr) return TEMPO_E_NULL;
+    a.views[v] = static_cast<const float*>(views[v]);
+  }
+  for (int v = V; v < TEMPO_MAX_VIEWS; v++) a.views[v] = nullptr;
+  a.out = out;
+  a.V = V; a.B = B; a.C_total = C_total; a.c_begin = c_begin; a.C = C;
+  a.HW = H * W; a.CP = CP;
+  dim3 grid((a.HW + kRepackPix - 1) / kRepackPix, V, B);
+  hipLaunchKernelGGL(repack_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int tempo_unproject_root(const float* hm, const float* cam, const float* ax_x,
+                         const float* ax_y, const float* ax_z, int ax_batched,
+                         const uint8_t* live, float* cubes, float* grids, void* mask,
+                         int mask_bytes, int B, int V, int C, int CP, int H, int W, int X,
+                         int Y, int Z, float hm_w, float hm_h, float img_w, float img_h,
+                         void* stream) {
+  if (!hm || !cam || !ax_x || !ax_y || !ax_z || !cubes) return TEMPO_E_NULL;
+  const int rc = check_common(V, C, CP, H, W);
+  if (rc != TEMPO_OK) return rc;
+  if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0) return TEMPO_E_DIM;
+  const long long N = (long long)X * Y * Z;
+  if (N * 4 >= 0x80000000LL) return TEMPO_E_SIZE;
+  if ((mask == nullptr) != (mask_bytes == 0)) return TEMPO_E_ARG;
+  if (mask && !((mask_bytes == 1 && V <= 8) || (mask_bytes == 2 && V <= 16) ||
+                mask_bytes == 4))
+    return TEMPO_E_ARG;
+  UnprojArgs a = {};
+  a.hm = hm; a.cam = cam;
+  a.ax[0] = ax_x; a.ax[1] = ax_y; a.ax[2] = ax_z;
+  a.ax_stride[0] = ax_batched ? X : 0;
+  a.ax_stride[1] = ax_batched ? Y : 0;
+  a.ax_stride[2] = ax_batched ? Z : 0;
+  a.live = live; a.cubes = cubes; a.grids = grids; a.mask = mask;
+  a.mask_bytes = mask_bytes;
+  a.frame_stride = (long long)V * H * W * CP;
+  a.view_bytes = (unsigned)((long long)H * W * CP * 4);
+  a.NB = B; a.F = B; a.V = V; a.C = C; a.CP = CP; a.H = H; a.W = W;
+  a.dim[0] = X; a.dim[1] = Y; a.dim[2] = Z; a.N = (int)N;
+  a.hm_w = hm_w; a.hm_h = hm_h; a.img_w = img_w; a.img_h = img_h;
+  return launch_mode<MODE_ROOT>(a, (hipStream_t)stream);
+}
+
+int tempo_unproject_window(const float* hm, const float* cam, const int32_t* win_frame,
+                           const float* fx, const float* fy, const float* fz,
+                           const int32_t* tl, const int32_t* start, const int32_t* end,
+                           const uint8_t* live, float* cubes, int NW, int F, int V, int C,
+                           int CP, int H, int W, int FX, int FY, int FZ, int VX, int VY,
+                           int VZ, float hm_w, float hm_h, float img_w, float img_h,
+                           void* stream) {
+  if (!hm || !cam || !fx || !fy || !fz || !tl || !start || !end || !cubes)
+    return TEMPO_E_NULL;
+  const int rc = check_common(V, C, CP, H, W);
+  if (rc != TEMPO_OK) return rc;
+  if (NW <= 0 || F <= 0 || FX <= 0 || FY <= 0 || FZ <= 0 || VX <= 0 || VY <= 0 || VZ <= 0)
+    return TEMPO_E_DIM;
+  if (win_frame == nullptr && NW != F) return TEMPO_E_ARG;
+  const long long N = (long long)VX * VY * VZ;
+  if (N * 4 >= 0x80000000LL) return TEMPO_E_SIZE;
+  UnprojArgs a = {};
+  a.hm = hm; a.cam = cam;
+  a.ax[0] = fx; a.ax[1] = fy; a.ax[2] = fz;
+  a.live = live; a.win_frame = win_frame; a.tl = tl; a.start = start; a.end = end;
+  a.cubes = cubes;
+  a.frame_stride = (long long)V * H * W * CP;
+  a.view_bytes = (unsigned)((long long)H * W * CP * 4);
+  a.NB = NW; a.F = F; a.V = V; a.C = C; a.CP = CP; a.H = H; a.W = W;
+  a.dim[0] = VX; a.dim[1] = VY; a.dim[2] = VZ; a.N = (int)N;
+  a.fdim[0] = FX; a.fdim[1] = FY; a.fdim[2] = FZ;
+  a.hm_w = hm_w; a.hm_h = hm_h; a.img_w = img_w; a.img_h = img_h;
+  return launch_mode<MODE_WINDOW>(a, (hipStream_t)stream);
+}
+
+int tempo_project_points(const float* pts, const float* cam, int M, int N, float hm_w,
+                         float hm_h, float img_w, float img_h, float* pix, float* grid,
+                         uint8_t* inside, void* stream) {
+  if (!pts || !cam || !pix || !grid || !inside) return TEMPO_E_NULL;
+  if (M <= 0 || M > 65535 || N <= 0) return TEMPO_E_DIM;
+  dim3 g((N + kThreads - 1) / kThreads, M);
+  hipLaunchKernelGGL(project_points_kernel, g, dim3(kThreads), 0, (hipStream_t)stream, pts,
+                     cam, N, hm_w, hm_h, img_w, img_h, pix, grid, inside);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

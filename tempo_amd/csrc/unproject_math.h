@@ -1,0 +1,165 @@
+// Per-voxel arithmetic of the unprojection path, shared by every kernel.
+//
+// The operation ORDER below is the contract: it reproduces, rounding step by
+// rounding step, what the reference's chain of fp32 torch ops computes on the
+// CPU (tempo/models/project_layer.py:111-126 and :255-268 of the reference,
+// plus mmpose's SimpleCameraTorch.world_to_pixel / affine_transform_torch and
+// torch's grid_sample unnormalisation).  Small-K matmuls there run as an FMA
+// chain ascending in k that starts with a plain multiply (probed against
+// torch 2.10 CPU); element-wise torch ops round after every operation.  The
+// file is compiled with -ffp-contract=off and every fused step is an explicit
+// fmaf(), so neither hipcc nor gcc may re-associate or fuse anything.
+//
+// TEMPO_HD lets tests/emul build the same functions with gcc for a CPU-side
+// bit-level comparison against the oracle; the product only ever runs them
+// on the GPU.
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TEMPO_HD __host__ __device__ __forceinline__
+#else
+#include <math.h>
+#define TEMPO_HD static inline
+#endif
+
+// Packed per-(batch item, view) parameter record, 32 floats = 128 B.
+// include/tempo_unproject.h documents the same layout for callers.
+enum {
+  CAM_R = 0,       // 9: R[k][j], row-major, used as X(row) @ R
+  CAM_T = 9,       // 3: T_w2c = -(T^T @ R)
+  CAM_K = 12,      // 6: K[0][0..2], K[1][0..2]  (pix = [x y 1] @ K^T)
+  CAM_KD = 18,     // 3: radial k0 k1 k2
+  CAM_PD = 21,     // 2: tangential p0 p1
+  CAM_HASD = 23,   // 1: != 0 when k and p are present
+  CAM_TRANS = 24,  // 6: 2x3 image affine (get_affine_transform)
+  CAM_WIDTH = 30,  // center[0] * 2
+  CAM_HEIGHT = 31, // center[1] * 2
+  CAM_FLOATS = 32
+};
+
+typedef struct TempoPix {
+  float px, py;  // source-image pixel (before the clamp)
+  int inside;    // bounds test of project_layer.py:113-115
+} TempoPix;
+
+TEMPO_HD float tempo_nan_clamp(float v, float lo, float hi) {
+  // torch.clamp: NaN stays NaN
+  if (v != v) return v;
+  v = v < lo ? lo : v;
+  return v > hi ? hi : v;
+}
+
+// world point -> source-image pixel (SimpleCameraTorch.world_to_pixel)
+TEMPO_HD TempoPix tempo_world_to_pixel(const float* __restrict__ cam, float x,
+                                       float y, float z) {
+  const float* R = cam + CAM_R;
+  // X @ R_w2c (fma chain, ascending k) then + T_w2c (separate add)
+  float xc = fmaf(z, R[6], fmaf(y, R[3], x * R[0])) + cam[CAM_T + 0];
+  float yc = fmaf(z, R[7], fmaf(y, R[4], x * R[1])) + cam[CAM_T + 1];
+  float zc = fmaf(z, R[8], fmaf(y, R[5], x * R[2])) + cam[CAM_T + 2];
+  // _X = X / X[..., 2:]   (no z > 0 test, as the reference)
+  float xn = xc / zc;
+  float yn = yc / zc;
+  float zn = zc / zc;
+  if (cam[CAM_HASD] != 0.0f) {
+    const float k0 = cam[CAM_KD], k1 = cam[CAM_KD + 1], k2 = cam[CAM_KD + 2];
+    const float p0 = cam[CAM_PD], p1 = cam[CAM_PD + 1];
+    float r2 = xn * xn + yn * yn;
+    float r4 = r2 * r2;        // r2**2
+    float r6 = r4 * r2;        // r2**3 = (r2*r2)*r2
+    float radial = 1.0f + ((k0 * r2 + k1 * r4) + k2 * r6);
+    float tang = 2.0f * (p1 * xn + p0 * yn);
+    float rt = radial + tang;
+    float xd = xn * rt + r2 * p1;
+    float yd = yn * rt + r2 * p0;
+    xn = xd;
+    yn = yd;
+  }
+  const float* K = cam + CAM_K;
+  TempoPix o;
+  o.px = fmaf(zn, K[2], fmaf(yn, K[1], xn * K[0]));
+  o.py = fmaf(zn, K[5], fmaf(yn, K[4], xn * K[3]));
+  o.inside = (o.px >= 0.0f) & (o.py >= 0.0f) & (o.px < cam[CAM_WIDTH]) &
+             (o.py < cam[CAM_HEIGHT]);
+  return o;
+}
+
+// source-image pixel -> grid_sample coordinate in [-1.1, 1.1]
+// (project_layer.py:116-126).  hm_w/hm_h are the module's heatmap_size,
+// img_w/img_h its image_size.
+TEMPO_HD void tempo_pixel_to_grid(const float* __restrict__ cam, float px,
+                                  float py, float hm_w, float hm_h, float img_w,
+                                  float img_h, float* gx, float* gy) {
+  const float wmax = cam[CAM_WIDTH] > cam[CAM_HEIGHT] ? cam[CAM_WIDTH]
+                                                      : cam[CAM_HEIGHT];
+  px = tempo_nan_clamp(px, -1.0f, wmax);
+  py = tempo_nan_clamp(py, -1.0f, wmax);
+  const float* t = cam + CAM_TRANS;
+  // torch.mm(t, [x y 1]^T): fma chain ascending in k
+  float ax = fmaf(t[2], 1.0f, fmaf(t[1], py, t[0] * px));
+  float ay = fmaf(t[5], 1.0f, fmaf(t[4], py, t[3] * px));
+  ax = (ax * hm_w) / img_w;
+  ay = (ay * hm_h) / img_h;
+  float sx = (ax / (hm_w - 1.0f)) * 2.0f - 1.0f;
+  float sy = (ay / (hm_h - 1.0f)) * 2.0f - 1.0f;
+  *gx = tempo_nan_clamp(sx, -1.1f, 1.1f);
+  *gy = tempo_nan_clamp(sy, -1.1f, 1.1f);
+}
+
+// grid_sample(align_corners=False) unnormalisation ((g + 1) * size - 1) / 2.
+// torch's vectorised CPU kernel evaluates it as (g + 1) * (size / 2) - 0.5 and
+// its build contracts the multiply-subtract into one FMA (probed bit-exact).
+TEMPO_HD float tempo_unnormalize(float g, float size) {
+  return fmaf(g + 1.0f, size * 0.5f, -0.5f);
+}
+
+// Bilinear footprint of one sample: top-left texel and the four weights, with
+// the weight of any texel outside [0,W)x[0,H) forced to zero (padding_mode=
+// 'zeros': an outside texel reads as 0, and 0 * w == w' * 0, so zeroing the
+// weight instead of the value is exact).  NaN coordinates give x0 = y0 = 0 and
+// NaN weights, which poison the sample like torch's arithmetic does.
+typedef struct TempoTap {
+  int x0, y0;             // top-left texel, may be outside the map
+  float nw, ne, sw, se;   // weights of (x0,y0) (x0+1,y0) (x0,y0+1) (x0+1,y0+1)
+} TempoTap;
+
+TEMPO_HD TempoTap tempo_bilinear_tap(float gx, float gy, int W, int H) {
+  float ix = tempo_unnormalize(gx, (float)W);
+  float iy = tempo_unnormalize(gy, (float)H);
+  float fx = floorf(ix), fy = floorf(iy);
+  float w = ix - fx, e = 1.0f - w;
+  float n = iy - fy, s = 1.0f - n;
+  TempoTap t;
+  // |g| <= 1.1 keeps ix, iy far inside int range; NaN falls to 0
+  t.x0 = (ix == ix) ? (int)fx : 0;
+  t.y0 = (iy == iy) ? (int)fy : 0;
+  t.nw = s * e;
+  t.ne = s * w;
+  t.sw = n * e;
+  t.se = n * w;
+  return t;
+}
+
+// sample = fma(se_val, se, fma(sw_val, sw, fma(ne_val, ne, nw_val * nw)))
+// (the contraction torch's CPU grid_sample is built with)
+TEMPO_HD float tempo_bilinear_mix(float a, float b, float c, float d, float nw,
+                                  float ne, float sw, float se) {
+  return fmaf(d, se, fmaf(c, sw, fmaf(b, ne, a * nw)));
+}
+
+// Order in which torch's CPU sum(dim=-1) adds the V per-view terms (probed on
+// torch 2.10: rows shorter than one 8-float vector go through a 4-way
+// interleaved scalar sum, longer rows add the tail first, then the vector's
+// lanes).  slot -> view; slots >= V are empty.  From V = 16 on the vector path
+// also pre-adds lane pairs; there the kernel sums views in index order, which
+// differs from torch by rounding only.
+TEMPO_HD int tempo_view_of_slot(int slot, int V) {
+  if (slot >= V) return -1;
+  if (V < 8) {
+    if (V < 5 || slot == 0) return slot;
+    return slot <= V - 4 ? slot + 3 : slot - (V - 4);
+  }
+  if (V < 16) return slot < V - 8 ? slot + 8 : slot - (V - 8);
+  return slot;
+}

@@ -1,0 +1,183 @@
+"""Functional layer over the C ABI: torch tensors in, torch tensors out.
+
+Everything here is plumbing (device memory, streams, argument checks); the
+arithmetic happens in ``csrc/tempo_unproject.hip``.  All entry points require
+CUDA/HIP tensors and raise otherwise -- there is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need(t, dtype, name, device=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError(f'{name}: expected a tensor on a HIP device (tempo_amd has no CPU path)')
+    if t.dtype != dtype:
+        raise TypeError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name}: must be contiguous')
+    if device is not None and t.device != device:
+        raise ValueError(f'{name}: on {t.device}, expected {device}')
+    return t
+
+
+def padded_channels(channels):
+    cp = _lib.load().tempo_padded_channels(int(channels))
+    _lib.check(min(cp, 0), 'tempo_padded_channels')
+    return cp
+
+
+def repack_nhwc(feature_maps, c_begin=0, channels=None, out=None):
+    """List of V fp32 ``[B,C,H,W]`` tensors -> ``[B,V,H,W,CP]`` channel-last."""
+    lib = _lib.load()
+    V = len(feature_maps)
+    fm0 = feature_maps[0]
+    dev = fm0.device
+    B, C_total, H, W = fm0.shape
+    C = C_total - c_begin if channels is None else channels
+    CP = padded_channels(C)
+    keep = []
+    for i, fm in enumerate(feature_maps):
+        if tuple(fm.shape) != (B, C_total, H, W):
+            raise ValueError('feature maps of all views must share one shape')
+        if fm.dtype != torch.float32:
+            fm = fm.float()  # the reference's force_fp32
+        keep.append(_need(fm.contiguous(), torch.float32, f'feature_maps[{i}]', dev))
+    if out is None:
+        out = torch.empty(B, V, H, W, CP, dtype=torch.float32, device=dev)
+    else:
+        _need(out, torch.float32, 'out', dev)
+        if out.numel() != B * V * H * W * CP:
+            raise ValueError('out has the wrong size')
+    ptrs = (ctypes.c_void_p * V)(*[fm.data_ptr() for fm in keep])
+    with torch.cuda.device(dev):
+        rc = lib.tempo_repack_nhwc(ptrs, V, B, C_total, c_begin, C, H, W, CP,
+                                   _ptr(out), _stream_ptr(dev))
+    _lib.check(rc, 'tempo_repack_nhwc')
+    return out
+
+
+def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
+                   want_grids=False, want_mask=False, out=None):
+    """Root-grid unprojection on a repacked heatmap tensor.
+
+    hm ``[B,V,H,W,CP]``; cam ``[B,V,32]``; axes = (ax_x, ax_y, ax_z), each
+    ``[X]`` (shared) or ``[B,X]`` (per batch item).  Returns
+    ``(cubes [B,C,X,Y,Z], grids [B,N,3] | None, mask [B,N] | None)``.
+    """
+    lib = _lib.load()
+    dev = hm.device
+    _need(hm, torch.float32, 'hm')
+    B, V, H, W, CP = hm.shape
+    _need(cam, torch.float32, 'cam', dev)
+    if tuple(cam.shape) != (B, V, 32):
+        raise ValueError(f'cam must be [{B},{V},32], got {tuple(cam.shape)}')
+    ax = [_need(a, torch.float32, 'axes', dev) for a in axes]
+    batched = ax[0].dim() == 2
+    for a in ax:
+        if (a.dim() == 2) != batched or (batched and a.shape[0] != B):
+            raise ValueError('axes must be all [n] or all [B,n]')
+    X, Y, Z = (int(a.shape[-1]) for a in ax)
+    N = X * Y * Z
+    C = int(channels)
+    if live is not None:
+        _need(live, torch.uint8, 'live', dev)
+        if live.numel() != B:
+            raise ValueError('live must have B entries')
+    if out is None:
+        out = torch.empty(B, C, X, Y, Z, dtype=torch.float32, device=dev)
+    else:
+        _need(out, torch.float32, 'out', dev)
+        if out.numel() != B * C * N:
+            raise ValueError('out has the wrong size')
+    grids = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if want_grids else None
+    mask, mask_bytes = None, 0
+    if want_mask:
+        mask_bytes = 1 if V <= 8 else (2 if V <= 16 else 4)
+        mdt = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[mask_bytes]
+        mask = torch.empty(B, N, dtype=mdt, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.tempo_unproject_root(
+            _ptr(hm), _ptr(cam), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), int(batched),
+            _ptr(live), _ptr(out), _ptr(grids), _ptr(mask), mask_bytes, B, V, C, CP, H, W,
+            X, Y, Z, float(heatmap_size[0]), float(heatmap_size[1]),
+            float(image_size[0]), float(image_size[1]), _stream_ptr(dev))
+    _lib.check(rc, 'tempo_unproject_root')
+    return out, grids, mask
+
+
+def unproject_window(hm, cam, fine_axes, tl, start, end, sub_cube, channels,
+                     heatmap_size, image_size, win_frame=None, live=None, out=None):
+    """Per-person window unprojection.  hm ``[F,V,H,W,CP]``, cam ``[F,V,32]``,
+    tl/start/end int32 ``[NW,3]``, win_frame int32 ``[NW]`` or None (NW == F).
+    Returns cubes ``[NW,C,VX,VY,VZ]``."""
+    lib = _lib.load()
+    dev = hm.device
+    _need(hm, torch.float32, 'hm')
+    F_, V, H, W, CP = hm.shape
+    _need(cam, torch.float32, 'cam', dev)
+    if tuple(cam.shape) != (F_, V, 32):
+        raise ValueError(f'cam must be [{F_},{V},32], got {tuple(cam.shape)}')
+    fa = [_need(a, torch.float32, 'fine_axes', dev) for a in fine_axes]
+    NW = int(tl.shape[0])
+    for name, t in (('tl', tl), ('start', start), ('end', end)):
+        _need(t, torch.int32, name, dev)
+        if tuple(t.shape) != (NW, 3):
+            raise ValueError(f'{name} must be [{NW},3]')
+    if win_frame is not None:
+        _need(win_frame, torch.int32, 'win_frame', dev)
+        if win_frame.numel() != NW:
+            raise ValueError('win_frame must have one entry per window')
+    elif NW != F_:
+        raise ValueError('without win_frame there must be one window per frame')
+    if live is not None:
+        _need(live, torch.uint8, 'live', dev)
+        if live.numel() != NW:
+            raise ValueError('live must have one entry per window')
+    VX, VY, VZ = (int(v) for v in sub_cube)
+    C = int(channels)
+    if out is None:
+        out = torch.empty(NW, C, VX, VY, VZ, dtype=torch.float32, device=dev)
+    else:
+        _need(out, torch.float32, 'out', dev)
+        if out.numel() != NW * C * VX * VY * VZ:
+            raise ValueError('out has the wrong size')
+    with torch.cuda.device(dev):
+        rc = lib.tempo_unproject_window(
+            _ptr(hm), _ptr(cam), _ptr(win_frame), _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]),
+            _ptr(tl), _ptr(start), _ptr(end), _ptr(live), _ptr(out), NW, F_, V, C, CP, H,
+            W, int(fa[0].numel()), int(fa[1].numel()), int(fa[2].numel()), VX, VY, VZ,
+            float(heatmap_size[0]), float(heatmap_size[1]), float(image_size[0]),
+            float(image_size[1]), _stream_ptr(dev))
+    _lib.check(rc, 'tempo_unproject_window')
+    return out
+
+
+def project_points(pts, cam, heatmap_size, image_size):
+    """pts ``[N,3]``, cam ``[M,32]`` -> (pix ``[M,N,2]``, grid ``[M,N,2]``,
+    inside ``[M,N]`` uint8): the coordinate chain alone, for parity checks."""
+    lib = _lib.load()
+    dev = pts.device
+    _need(pts, torch.float32, 'pts')
+    _need(cam, torch.float32, 'cam', dev)
+    N, M = int(pts.shape[0]), int(cam.shape[0])
+    pix = torch.empty(M, N, 2, dtype=torch.float32, device=dev)
+    grid = torch.empty(M, N, 2, dtype=torch.float32, device=dev)
+    inside = torch.empty(M, N, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.tempo_project_points(
+            _ptr(pts), _ptr(cam), M, N, float(heatmap_size[0]), float(heatmap_size[1]),
+            float(image_size[0]), float(image_size[1]), _ptr(pix), _ptr(grid),
+            _ptr(inside), _stream_ptr(dev))
+    _lib.check(rc, 'tempo_project_points')
+    return pix, grid, inside

@@ -1,0 +1,262 @@
+"""Drop-in ``ProjectLayer`` / ``ProjectLayerWithMask`` backed by the HIP kernels.
+
+Same constructor arguments, ``forward`` signatures, return tuples and public
+attributes as ``tempo/models/project_layer.py`` of the reference (``:18-158``
+and ``:160-388``), so ``tempo_detector.py:47,187-190`` and
+``tempo_pose.py:41-46,152-162`` can use these classes unchanged.
+
+Differences, all deliberate:
+
+* HIP devices only.  There is no CPU / PyTorch fallback: CPU tensors raise.
+* Forward only.  Feature maps that require grad (training with
+  ``freeze_2d=False``) raise ``NotImplementedError`` instead of silently
+  detaching.
+* ``agg_method`` must be ``'mean'`` (what every config uses; the reference's
+  ``'learned'`` branch is hard-wired to 5 views x 32 channels in ``ProjectLayer``
+  and references undefined names in ``ProjectLayerWithMask``, ``:360-366``).
+* camera dicts with ``'intrinsics'`` raise ``NotImplementedError`` (the
+  reference would hit a ``NameError``: ``FisheyeCameraTorch`` is undefined).
+* an error in sampling raises instead of dropping into ``pdb`` (``:285-286``).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .camera import pack_cameras
+
+
+def _pair(v):
+    return [v, v] if isinstance(v, int) else v
+
+
+def _triple(v, kinds):
+    return [v, v, v] if isinstance(v, kinds) else v
+
+
+def _check_inputs(feature_maps):
+    fm0 = feature_maps[0]
+    if not fm0.is_cuda:
+        raise RuntimeError('tempo_amd.ProjectLayer runs on HIP devices only; got a '
+                           f'{fm0.device} tensor (there is no CPU fallback)')
+    if torch.is_grad_enabled() and any(fm.requires_grad for fm in feature_maps):
+        raise NotImplementedError(
+            'tempo_amd unprojection is forward-only; run under torch.no_grad() or '
+            'detach the feature maps')
+    return fm0.device
+
+
+def _base_axis(size, bins):
+    """``torch.linspace(-size/2, size/2, bins)`` exactly as compute_grid calls it
+    (on the CPU: torch's CPU linspace is the oracle's arithmetic)."""
+    return torch.linspace(-size / 2, size / 2, bins)
+
+
+class _Slices:
+    """channel slices of at most 32 (one kernel call each)"""
+
+    def __init__(self, channels):
+        self.items = [(c0, min(32, channels - c0)) for c0 in range(0, channels, 32)]
+
+
+class ProjectLayer(nn.Module):
+    """Root-grid unprojection, ``project_layer.py:18-158``."""
+
+    def __init__(self, image_size, heatmap_size, agg_method='mean'):
+        super().__init__()
+        if agg_method != 'mean':
+            raise NotImplementedError(f"agg_method={agg_method!r}: only 'mean' is supported")
+        self.image_size = _pair(image_size)
+        self.heatmap_size = _pair(heatmap_size)
+        self.agg_method = agg_method
+        self.last_mask = None  # valid-view bitmap of the last call when keep_mask
+        self.keep_mask = False
+        self.materialize_grids = True  # the reference's 2nd return; callers drop it
+
+    def compute_grid(self, box_size, box_center, num_bins, device=None):
+        """``project_layer.py:43-63``: ``[N,3]`` voxel centres, z fastest."""
+        box_size = _triple(box_size, (int, float))
+        num_bins = _triple(num_bins, int)
+        ax = [(_base_axis(box_size[i], num_bins[i]) + box_center[i]).to(device)
+              for i in range(3)]
+        gx, gy, gz = torch.meshgrid(*ax, indexing='ij')
+        return torch.stack([gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)], dim=1)
+
+    def _axes(self, grid_size, grid_center, cube_size, B, device):
+        grid_size = _triple(grid_size, (int, float))
+        cube_size = _triple(cube_size, int)
+        base = [_base_axis(grid_size[i], cube_size[i]) for i in range(3)]
+        if len(grid_center) == 1:
+            gc = grid_center[0]
+            return [(base[i] + float(gc[i])).to(device) for i in range(3)], cube_size
+        if isinstance(grid_center, torch.Tensor):
+            gc = grid_center[:, :3].to(device=device, dtype=torch.float32)
+        else:
+            gc = torch.tensor([[float(c[i]) for i in range(3)] for c in grid_center],
+                              dtype=torch.float32, device=device)
+        if gc.shape[0] != B:
+            raise IndexError('grid_center needs 1 or batch_size entries')
+        return [(base[i].to(device)[None, :] + gc[:, i:i + 1]).contiguous()
+                for i in range(3)], cube_size
+
+    def _live(self, grid_center, B, device):
+        """skip rule of ``project_layer.py:81``."""
+        if len(grid_center[0]) == 3:
+            return None
+        if isinstance(grid_center, torch.Tensor):
+            return (grid_center[:B, 3] >= 0).to(device=device, dtype=torch.uint8).contiguous()
+        flags = [1 if float(grid_center[b][3]) >= 0 else 0 for b in range(B)]
+        return None if all(flags) else torch.tensor(flags, dtype=torch.uint8, device=device)
+
+    def get_voxel(self, feature_maps, grid_size, grid_center, cube_size, centers,
+                  scales, cameras):
+        device = _check_inputs(feature_maps)
+        B, C = feature_maps[0].shape[:2]
+        live = self._live(grid_center, B, device)
+        axes, cube_size = self._axes(grid_size, grid_center, cube_size, B, device)
+        cam = pack_cameras(centers, scales, cameras, self.image_size).to(device)
+        cubes = torch.empty(B, C, *cube_size, dtype=torch.float32, device=device)
+        grids = mask = None
+        for c0, cs in _Slices(C).items:
+            hm = ops.repack_nhwc(feature_maps, c0, cs)
+            first = c0 == 0
+            out, g, m = ops.unproject_root(
+                hm, cam, axes, cs, self.heatmap_size, self.image_size, live=live,
+                want_grids=first and self.materialize_grids,
+                want_mask=first and self.keep_mask,
+                out=cubes if cs == C else None)
+            if cs != C:
+                cubes[:, c0:c0 + cs] = out
+            if first:
+                grids, mask = g, m
+        self.last_mask = mask
+        return cubes, grids
+
+    def forward(self, feature_maps, grid_size, grid_center, cube_size, centers,
+                scales, cameras):
+        return self.get_voxel(feature_maps, grid_size, grid_center, cube_size,
+                              centers, scales, cameras)
+
+
+class ProjectLayerWithMask(nn.Module):
+    """Per-person window unprojection, ``project_layer.py:160-388``."""
+
+    def __init__(self, image_size, heatmap_size, agg_method='mean'):
+        super().__init__()
+        if agg_method != 'mean':
+            raise NotImplementedError(f"agg_method={agg_method!r}: only 'mean' is supported")
+        self.image_size = _pair(image_size)
+        self.heatmap_size = _pair(heatmap_size)
+        self.agg_method = agg_method
+        self._fine_axes = None  # (device axes, cpu axes); cached like fine_grid is
+        self._fine_grid = None
+        self.center_grid = None
+
+    # the reference caches ``fine_grid`` ([fx*fy*fz, 3], 49 MB at the Panoptic
+    # sizes) at the first call and never refreshes it; only its three axis
+    # vectors are needed here, the full grid is built on first access.
+    @property
+    def fine_grid(self):
+        if self._fine_grid is None and self._fine_axes is not None:
+            gx, gy, gz = torch.meshgrid(*self._fine_axes, indexing='ij')
+            self._fine_grid = torch.stack(
+                [gx.reshape(-1), gy.reshape(-1), gz.reshape(-1)], dim=1)
+        return self._fine_grid
+
+    def set_space_size(self, space_center, space_size, sub_space_size,
+                       sub_cube_size, device):
+        """``project_layer.py:184-201``, same tensor ops on ``device``."""
+        self.whole_space_center = torch.tensor(space_center, device=device)
+        self.whole_space_size = torch.tensor(space_size, device=device)
+        self.ind_space_size = torch.tensor(sub_space_size, device=device)
+        self.voxels_per_axis = torch.tensor(sub_cube_size, device=device,
+                                            dtype=torch.int32)
+        self.fine_voxels_per_axis = (self.whole_space_size / self.ind_space_size *
+                                     (self.voxels_per_axis - 1)).int() + 1
+        self.scale = (self.fine_voxels_per_axis.float() - 1) / self.whole_space_size
+        self.bias = (-self.ind_space_size / 2.0 / self.whole_space_size *
+                     (self.fine_voxels_per_axis - 1) - self.scale *
+                     (self.whole_space_center - self.whole_space_size / 2.0))
+        self.num_bins = (self.voxels_per_axis[0] * self.voxels_per_axis[1] *
+                         self.voxels_per_axis[2])
+        self.num_fine_bins = (self.fine_voxels_per_axis[0] *
+                              self.fine_voxels_per_axis[1] *
+                              self.fine_voxels_per_axis[2])
+        # host copies of the integer geometry (same ops on CPU tensors, no sync)
+        ws = torch.tensor(space_size)
+        ins = torch.tensor(sub_space_size)
+        vpa = torch.tensor(sub_cube_size, dtype=torch.int32)
+        self._sub_cube = [int(v) for v in vpa]
+        self._fine_bins = [int(v) for v in ((ws / ins * (vpa - 1)).int() + 1)]
+        self._space = (list(space_center), list(space_size), list(sub_space_size))
+
+    def compute_grid(self, box_size, box_center, num_bins, device=None):
+        return ProjectLayer.compute_grid(self, box_size, box_center, num_bins, device)
+
+    def window_geometry(self, grid_center):
+        """``project_layer.py:299-324``: (centers_tl, offset, start, end)."""
+        device = grid_center.device
+        B = grid_center.shape[0]
+        centers_tl = torch.round(grid_center[:, :3].float() * self.scale +
+                                 self.bias).int()
+        offset = (centers_tl.float() / (self.fine_voxels_per_axis - 1) *
+                  self.whole_space_size - self.whole_space_size / 2.0 +
+                  self.ind_space_size / 2.0)
+        mask = ((1 - grid_center[:, 5:7]) / 2 * (self.voxels_per_axis[0:2] - 1)).int()
+        mask[mask < 0] = 0
+        mask = torch.cat(
+            [mask, torch.zeros((B, 1), device=device, dtype=torch.int32)], dim=1)
+        start = torch.where(centers_tl + mask >= 0, centers_tl + mask,
+                            torch.zeros_like(centers_tl))
+        end = torch.where(
+            centers_tl + self.voxels_per_axis - mask <= self.fine_voxels_per_axis,
+            centers_tl + self.voxels_per_axis - mask, self.fine_voxels_per_axis)
+        end = torch.maximum(end, start + 1)
+        return centers_tl, offset, start, end
+
+    def _ensure_grids(self, device):
+        if self._fine_axes is not None:
+            return
+        center, size, sub = self._space
+        self._fine_axes = [
+            (_base_axis(size[i], self._fine_bins[i]) + center[i]).to(device)
+            for i in range(3)
+        ]
+        vx = self._sub_cube
+        ax = [_base_axis(sub[i], vx[i]) + center[i] for i in range(3)]
+        gx, gy, gz = torch.meshgrid(*ax, indexing='ij')
+        grid = torch.stack([gx, gy, gz], dim=-1)
+        self.center_grid = torch.stack([
+            grid[:, :, 0, :2].reshape(-1, 2), grid[:, 0, :, ::2].reshape(-1, 2),
+            grid[0, :, :, 1:].reshape(-1, 2)
+        ]).to(device)
+
+    def get_voxel(self, feature_maps, grid_center, centers, scales, cameras):
+        device = _check_inputs(feature_maps)
+        B, C = feature_maps[0].shape[:2]
+        if grid_center.device != device:
+            grid_center = grid_center.to(device)
+        centers_tl, offset, start, end = self.window_geometry(grid_center)
+        self._ensure_grids(device)
+        live = None
+        if grid_center.shape[1] != 3:
+            live = (grid_center[:, 3] >= 0).to(torch.uint8).contiguous()
+        cam = pack_cameras(centers, scales, cameras, self.image_size).to(device)
+        tl, st, en = (t.to(torch.int32).contiguous() for t in (centers_tl, start, end))
+        cubes = torch.empty(B, C, *self._sub_cube, dtype=torch.float32, device=device)
+        for c0, cs in _Slices(C).items:
+            hm = ops.repack_nhwc(feature_maps, c0, cs)
+            out = ops.unproject_window(
+                hm, cam, self._fine_axes, tl, st, en, self._sub_cube, cs,
+                self.heatmap_size, self.image_size, live=live,
+                out=cubes if cs == C else None)
+            if cs != C:
+                cubes[:, c0:c0 + cs] = out
+        return cubes, offset
+
+    def forward(self, feature_maps, grid_center, space_center, space_size,
+                sub_space_size, sub_cube_size, centers, scales, cameras):
+        device = feature_maps[0].device
+        self.set_space_size(space_center, space_size, sub_space_size,
+                            sub_cube_size, device)
+        return self.get_voxel(feature_maps, grid_center, centers, scales, cameras)

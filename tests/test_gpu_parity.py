@@ -1,0 +1,122 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle and the
+committed golden fixtures.  Bars (BASELINE.json north_star): volume max-abs
+error <= 1e-5 in fp32, valid-view mask bit-exact.  The kernels reproduce the
+oracle's operation order, so on hosts where torch's CPU kernels contract FMAs
+the way the probed build does the error is exactly 0; the assertion is the
+stated tolerance."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import project_layer_ref as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _bits(bounding):
+    V = bounding.shape[-1]
+    return (bounding.to(torch.int32) << torch.arange(V, dtype=torch.int32)).sum(-1)
+
+
+def _report(name, got, ref):
+    d = (got - ref).abs()
+    nz = int((got != ref).sum())
+    print(f'\n[{name}] max-abs {float(d.max()):.3e}  differing elements {nz}/{ref.numel()}')
+    return float(d.max())
+
+
+def test_library_loaded_from_tree():
+    from tempo_amd import _lib
+    lib = _lib.load()
+    assert lib.tempo_version() == 1
+    assert os.path.dirname(_lib.LIB_PATH).endswith(os.path.join('tempo_amd', 'lib'))
+
+
+@pytest.mark.parametrize('name', list(cases.ROOT_CASES))
+def test_root_vs_oracle_and_golden(name, gpu_device):
+    import tempo_amd
+    case = cases.build_root(name)
+    ref_layer = O.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, ref_grids = ref_layer(*case['args'])
+    ref_mask = _bits(ref_layer.last_bounding)
+
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    layer.keep_mask = True
+    dcase = cases.to_device(case, gpu_device)
+    with torch.no_grad():
+        cubes, grids = layer(*dcase['args'])
+    torch.cuda.synchronize()
+    assert cubes.shape == ref_cubes.shape and grids.shape == ref_grids.shape
+    assert _report(name, cubes.cpu(), ref_cubes) <= TOL
+    assert torch.equal(grids.cpu(), ref_grids)
+    assert torch.equal(layer.last_mask.cpu().to(torch.int32), ref_mask), 'valid-view mask'
+
+    gold = np.load(os.path.join(GOLD, name + '.npz'))
+    assert np.abs(cubes.cpu().numpy() - gold['cubes']).max() <= TOL
+    assert np.array_equal(layer.last_mask.cpu().numpy().astype(np.uint32), gold['mask'])
+
+
+@pytest.mark.parametrize('name', list(cases.WINDOW_CASES))
+def test_window_vs_oracle_and_golden(name, gpu_device):
+    import tempo_amd
+    case = cases.build_window(name)
+    ref_layer = O.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, ref_off = ref_layer(*case['args'])
+
+    layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    dcase = cases.to_device(case, gpu_device)
+    with torch.no_grad():
+        cubes, off = layer(*dcase['args'])
+    torch.cuda.synchronize()
+    assert cubes.shape == ref_cubes.shape
+    assert _report(name, cubes.cpu(), ref_cubes) <= TOL
+    assert torch.equal(off.cpu(), ref_off)
+    assert torch.equal(layer.center_grid.cpu(), ref_layer.center_grid)
+    assert torch.equal(layer.fine_grid.cpu(), ref_layer.fine_grid)
+
+    gold = np.load(os.path.join(GOLD, name + '.npz'))
+    assert np.abs(cubes.cpu().numpy() - gold['cubes']).max() <= TOL
+    assert np.array_equal(off.cpu().numpy(), gold['offset'])
+
+
+def test_projection_chain_bit_exact(gpu_device):
+    """pixel coordinates, sample-grid coordinates and the bounds test of the
+    kernels equal the oracle's torch ops bit for bit (Panoptic-like + H36M)."""
+    from tempo_amd import ops, synthetic as S
+    from tempo_amd.camera import pack_cameras
+    for cfg, cams in ((S.PANOPTIC, S.ring_cameras(5, seed=3)), (S.H36M, S.h36m_cameras())):
+        centers, scales, cameras = S.frame_meta(cams, 1, cfg['raw_size'], cfg['image_size'])
+        table = pack_cameras(centers, scales, cameras, cfg['image_size'])[0]
+        grid = O.compute_grid(cfg['space_size'], cfg['space_center'], cfg['cube_size'])
+        pix, g, inside = ops.project_points(grid.to(gpu_device), table.to(gpu_device),
+                                            cfg['heatmap_size'], cfg['image_size'])
+        w, h = cfg['heatmap_size']
+        for v, cam in enumerate(cams):
+            xy = O.SimpleCameraTorch(cam, 'cpu').world_to_pixel(grid)
+            width, height = centers[0][v] * 2
+            ins = (xy[:, 0] >= 0) & (xy[:, 1] >= 0) & (xy[:, 0] < width) & (xy[:, 1] < height)
+            trans = torch.as_tensor(
+                O.get_affine_transform(centers[0][v], scales[0][v] / 200.0, 0,
+                                       cfg['image_size']), dtype=torch.float)
+            sg = torch.clamp(O._sample_coords(xy, trans, w, h, cfg['image_size'], width,
+                                              height, 'cpu'), -1.1, 1.1)
+            assert torch.equal(inside[v].cpu().bool(), ins)
+            assert torch.equal(pix[v].cpu().view(torch.int32), xy.view(torch.int32))
+            assert torch.equal(g[v].cpu().view(torch.int32), sg.view(torch.int32))
+
+
+def test_repack_matches_permute(gpu_device):
+    from tempo_amd import ops
+    torch.manual_seed(5)
+    for (B, V, C, H, W) in ((2, 3, 15, 7, 37), (1, 2, 17, 16, 64), (2, 2, 32, 5, 13)):
+        fms = [torch.rand(B, C, H, W, device=gpu_device) for _ in range(V)]
+        out = ops.repack_nhwc(fms)
+        cp = out.shape[-1]
+        ref = torch.zeros(B, V, H, W, cp, device=gpu_device)
+        ref[..., :C] = torch.stack(fms, 1).permute(0, 1, 3, 4, 2)
+        assert torch.equal(out, ref)
