@@ -23,7 +23,10 @@
  *   [9..11]  T_w2c = -(T^T @ R)
  *   [12..17] K[0][0..2], K[1][0..2]        (pixel = [x y 1] @ K^T)
  *   [18..20] radial k0 k1 k2   [21..22] tangential p0 p1
- *   [23]     != 0 when the distortion terms apply
+ *   [23]     flags as a float: 1 = distortion terms apply; 2 / 4 / 8 = evaluate
+ *            X @ R / [x y 1] @ K^T / affine @ [x y 1]^T as three products and
+ *            two adds instead of multiply + two FMAs (the host BLAS flavour,
+ *            see tempo_amd/numerics.py)
  *   [24..29] 2x3 image affine (mmpose get_affine_transform(center, scale/200, 0, image_size))
  *   [30] width = center[0]*2   [31] height = center[1]*2
  * (what the reference rebuilds per (batch, view) at project_layer.py:97-110 and

@@ -18,7 +18,9 @@ so the table is bit-identical to what the reference's camera objects hold.
 import numpy as np
 import torch
 
-CAM_R, CAM_T, CAM_K, CAM_KD, CAM_PD, CAM_HASD, CAM_TRANS = 0, 9, 12, 18, 21, 23, 24
+from . import numerics
+
+CAM_R, CAM_T, CAM_K, CAM_KD, CAM_PD, CAM_FLAGS, CAM_TRANS = 0, 9, 12, 18, 21, 23, 24
 CAM_WIDTH, CAM_HEIGHT, CAM_FLOATS = 30, 31, 32
 
 
@@ -63,7 +65,28 @@ def affine_transforms(centers, scales, output_size):
     return np.linalg.solve(a, b[..., None])[..., 0].reshape(m, 2, 3)
 
 
-def _camera_record(param, out):
+def _t_w2c(T, R, mm_mode):
+    """``-(T^T @ R)`` of SimpleCameraTorch.  'auto': the torch op itself, i.e.
+    whatever the host BLAS does (exactly the reference on this machine).  A
+    pinned flavour is evaluated in float64, where every float32 product is
+    exact (an FMA is then one float64 add + one rounding to float32; the
+    double rounding can differ from a true FMA with probability ~2^-29)."""
+    if mm_mode is None or mm_mode == 'auto':
+        return (-(T.T) @ R).reshape(3)
+    flavour = numerics.resolve(mm_mode)['R']
+    t = T.reshape(3).numpy().astype(np.float64)
+    r = R.numpy().astype(np.float64)
+    # torch negates T first (exact), then multiplies: (-T)^T @ R
+    p = [(-t[k]) * r[k, :] for k in range(3)]
+    f = np.float32
+    if flavour == 'fma':
+        out = f(f(f(p[0]).astype(np.float64) + p[1]).astype(np.float64) + p[2])
+    else:
+        out = f(f(f(p[0]) + f(p[1])) + f(p[2]))
+    return torch.from_numpy(out.astype(np.float32))
+
+
+def _camera_record(param, out, mm_mode='auto'):
     """One ``SimpleCameraTorch.__init__`` worth of fields into ``out[0:24]``."""
     if 'intrinsics' in param:
         # the reference selects FisheyeCameraTorch here, a name defined nowhere
@@ -75,7 +98,7 @@ def _camera_record(param, out):
     if R.shape != (3, 3) or T.shape != (3, 1):
         raise ValueError(f'camera R/T must be 3x3 / 3x1, got {tuple(R.shape)} / {tuple(T.shape)}')
     out[CAM_R:CAM_R + 9] = R.reshape(9)
-    out[CAM_T:CAM_T + 3] = (-(T.T) @ R).reshape(3)
+    out[CAM_T:CAM_T + 3] = _t_w2c(T, R, mm_mode)
     if 'K' in param:
         K = torch.as_tensor(np.asarray(param['K'], dtype=np.float32))
         if K.shape != (2, 3):
@@ -100,12 +123,13 @@ def _camera_record(param, out):
         # branch tests ``k.size == 6`` on a tensor and never runs)
         out[CAM_KD:CAM_KD + 3] = torch.from_numpy(k[:3].copy())
         out[CAM_PD:CAM_PD + 2] = torch.from_numpy(p.copy())
-        out[CAM_HASD] = 1.0
+        out[CAM_FLAGS] += float(numerics.F_DIST)
 
 
-def pack_cameras(centers, scales, cameras, image_size):
+def pack_cameras(centers, scales, cameras, image_size, mm_mode='auto'):
     """``centers[b][v]``, ``scales[b][v]`` (np.float32 (2,)), ``cameras[b][v]``
-    (dict) -> CPU fp32 tensor ``[B,V,32]``."""
+    (dict) -> CPU fp32 tensor ``[B,V,32]``.  ``mm_mode``: rounding flavour of
+    the K=3 matmuls, see ``tempo_amd.numerics`` (default: as torch on this host)."""
     B = len(cameras)
     V = len(cameras[0])
     table = torch.zeros(B, V, CAM_FLOATS, dtype=torch.float32)
@@ -121,7 +145,7 @@ def pack_cameras(centers, scales, cameras, image_size):
             param = cameras[b][v]
             hit = seen.get(id(param))
             if hit is None:
-                _camera_record(param, table[b, v])
+                _camera_record(param, table[b, v], mm_mode)
                 seen[id(param)] = (b, v)
             else:
                 table[b, v, :CAM_TRANS] = table[hit[0], hit[1], :CAM_TRANS]
@@ -135,4 +159,5 @@ def pack_cameras(centers, scales, cameras, image_size):
     wh = torch.from_numpy(cen * 2)  # width, height = center * 2 (float32)
     flat[:, CAM_WIDTH] = wh[:, 0]
     flat[:, CAM_HEIGHT] = wh[:, 1]
+    flat[:, CAM_FLAGS] += float(numerics.flag_bits(mm_mode))
     return table

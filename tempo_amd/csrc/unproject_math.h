@@ -4,11 +4,16 @@
 // rounding step, what the reference's chain of fp32 torch ops computes on the
 // CPU (tempo/models/project_layer.py:111-126 and :255-268 of the reference,
 // plus mmpose's SimpleCameraTorch.world_to_pixel / affine_transform_torch and
-// torch's grid_sample unnormalisation).  Small-K matmuls there run as an FMA
-// chain ascending in k that starts with a plain multiply (probed against
-// torch 2.10 CPU); element-wise torch ops round after every operation.  The
-// file is compiled with -ffp-contract=off and every fused step is an explicit
-// fmaf(), so neither hipcc nor gcc may re-associate or fuse anything.
+// torch's grid_sample unnormalisation).  Element-wise torch ops round after
+// every operation.  The three K=3 matmuls (X @ R, [x y 1] @ K^T, trans @
+// [x y 1]^T) go through the host's BLAS, whose rounding differs between CPUs
+// (probed with torch 2.10 + MKL: an FMA chain ascending in k that starts with
+// a plain multiply on Intel, three products and two adds ascending in k on AMD
+// EPYC), so each site takes a flag that selects the flavour; tempo_amd.numerics
+// probes the host and sets the flags so that the kernels reproduce torch on
+// the machine they run on.  The file is compiled with -ffp-contract=off and
+// every fused step is an explicit fmaf(), so neither hipcc nor gcc may
+// re-associate or fuse anything.
 //
 // TEMPO_HD lets tests/emul build the same functions with gcc for a CPU-side
 // bit-level comparison against the oracle; the product only ever runs them
@@ -31,12 +36,27 @@ enum {
   CAM_K = 12,      // 6: K[0][0..2], K[1][0..2]  (pix = [x y 1] @ K^T)
   CAM_KD = 18,     // 3: radial k0 k1 k2
   CAM_PD = 21,     // 2: tangential p0 p1
-  CAM_HASD = 23,   // 1: != 0 when k and p are present
+  CAM_FLAGS = 23,  // 1: bit flags stored as a float (TEMPO_F_*)
   CAM_TRANS = 24,  // 6: 2x3 image affine (get_affine_transform)
   CAM_WIDTH = 30,  // center[0] * 2
   CAM_HEIGHT = 31, // center[1] * 2
   CAM_FLOATS = 32
 };
+
+// flags in cam[CAM_FLAGS]
+enum {
+  TEMPO_F_DIST = 1,        // k and p present: apply the distortion terms
+  TEMPO_F_UNFUSED_R = 2,   // X @ R        as mul,mul,mul,add,add (else mul,fma,fma)
+  TEMPO_F_UNFUSED_K = 4,   // [x y 1] @ K^T
+  TEMPO_F_UNFUSED_A = 8    // trans @ [x y 1]^T
+};
+
+// sum_k a_k * b_k, k ascending, in the flavour the host BLAS uses
+TEMPO_HD float tempo_dot3(float a0, float b0, float a1, float b1, float a2,
+                          float b2, int unfused) {
+  if (unfused) return (a0 * b0 + a1 * b1) + a2 * b2;
+  return fmaf(a2, b2, fmaf(a1, b1, a0 * b0));
+}
 
 typedef struct TempoPix {
   float px, py;  // source-image pixel (before the clamp)
@@ -54,15 +74,17 @@ TEMPO_HD float tempo_nan_clamp(float v, float lo, float hi) {
 TEMPO_HD TempoPix tempo_world_to_pixel(const float* __restrict__ cam, float x,
                                        float y, float z) {
   const float* R = cam + CAM_R;
-  // X @ R_w2c (fma chain, ascending k) then + T_w2c (separate add)
-  float xc = fmaf(z, R[6], fmaf(y, R[3], x * R[0])) + cam[CAM_T + 0];
-  float yc = fmaf(z, R[7], fmaf(y, R[4], x * R[1])) + cam[CAM_T + 1];
-  float zc = fmaf(z, R[8], fmaf(y, R[5], x * R[2])) + cam[CAM_T + 2];
+  const int flags = (int)cam[CAM_FLAGS];
+  const int uf_r = flags & TEMPO_F_UNFUSED_R, uf_k = flags & TEMPO_F_UNFUSED_K;
+  // X @ R_w2c then + T_w2c (separate add)
+  float xc = tempo_dot3(x, R[0], y, R[3], z, R[6], uf_r) + cam[CAM_T + 0];
+  float yc = tempo_dot3(x, R[1], y, R[4], z, R[7], uf_r) + cam[CAM_T + 1];
+  float zc = tempo_dot3(x, R[2], y, R[5], z, R[8], uf_r) + cam[CAM_T + 2];
   // _X = X / X[..., 2:]   (no z > 0 test, as the reference)
   float xn = xc / zc;
   float yn = yc / zc;
   float zn = zc / zc;
-  if (cam[CAM_HASD] != 0.0f) {
+  if (flags & TEMPO_F_DIST) {
     const float k0 = cam[CAM_KD], k1 = cam[CAM_KD + 1], k2 = cam[CAM_KD + 2];
     const float p0 = cam[CAM_PD], p1 = cam[CAM_PD + 1];
     float r2 = xn * xn + yn * yn;
@@ -78,8 +100,8 @@ TEMPO_HD TempoPix tempo_world_to_pixel(const float* __restrict__ cam, float x,
   }
   const float* K = cam + CAM_K;
   TempoPix o;
-  o.px = fmaf(zn, K[2], fmaf(yn, K[1], xn * K[0]));
-  o.py = fmaf(zn, K[5], fmaf(yn, K[4], xn * K[3]));
+  o.px = tempo_dot3(xn, K[0], yn, K[1], zn, K[2], uf_k);
+  o.py = tempo_dot3(xn, K[3], yn, K[4], zn, K[5], uf_k);
   o.inside = (o.px >= 0.0f) & (o.py >= 0.0f) & (o.px < cam[CAM_WIDTH]) &
              (o.py < cam[CAM_HEIGHT]);
   return o;
@@ -96,9 +118,10 @@ TEMPO_HD void tempo_pixel_to_grid(const float* __restrict__ cam, float px,
   px = tempo_nan_clamp(px, -1.0f, wmax);
   py = tempo_nan_clamp(py, -1.0f, wmax);
   const float* t = cam + CAM_TRANS;
-  // torch.mm(t, [x y 1]^T): fma chain ascending in k
-  float ax = fmaf(t[2], 1.0f, fmaf(t[1], py, t[0] * px));
-  float ay = fmaf(t[5], 1.0f, fmaf(t[4], py, t[3] * px));
+  // torch.mm(t, [x y 1]^T)
+  const int uf_a = (int)cam[CAM_FLAGS] & TEMPO_F_UNFUSED_A;
+  float ax = tempo_dot3(t[0], px, t[1], py, t[2], 1.0f, uf_a);
+  float ay = tempo_dot3(t[3], px, t[4], py, t[5], 1.0f, uf_a);
   ax = (ax * hm_w) / img_w;
   ay = (ay * hm_h) / img_h;
   float sx = (ax / (hm_w - 1.0f)) * 2.0f - 1.0f;

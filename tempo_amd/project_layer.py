@@ -18,7 +18,6 @@ Differences, all deliberate:
   reference would hit a ``NameError``: ``FisheyeCameraTorch`` is undefined).
 * an error in sampling raises instead of dropping into ``pdb`` (``:285-286``).
 """
-import numpy as np
 import torch
 import torch.nn as nn
 
@@ -69,6 +68,7 @@ class ProjectLayer(nn.Module):
         self.image_size = _pair(image_size)
         self.heatmap_size = _pair(heatmap_size)
         self.agg_method = agg_method
+        self.mm_mode = 'auto'  # rounding flavour of the K=3 matmuls (numerics.py)
         self.last_mask = None  # valid-view bitmap of the last call when keep_mask
         self.keep_mask = False
         self.materialize_grids = True  # the reference's 2nd return; callers drop it
@@ -114,7 +114,8 @@ class ProjectLayer(nn.Module):
         B, C = feature_maps[0].shape[:2]
         live = self._live(grid_center, B, device)
         axes, cube_size = self._axes(grid_size, grid_center, cube_size, B, device)
-        cam = pack_cameras(centers, scales, cameras, self.image_size).to(device)
+        cam = pack_cameras(centers, scales, cameras, self.image_size,
+                           self.mm_mode).to(device)
         cubes = torch.empty(B, C, *cube_size, dtype=torch.float32, device=device)
         grids = mask = None
         for c0, cs in _Slices(C).items:
@@ -148,7 +149,8 @@ class ProjectLayerWithMask(nn.Module):
         self.image_size = _pair(image_size)
         self.heatmap_size = _pair(heatmap_size)
         self.agg_method = agg_method
-        self._fine_axes = None  # (device axes, cpu axes); cached like fine_grid is
+        self.mm_mode = 'auto'  # rounding flavour of the K=3 matmuls (numerics.py)
+        self._fine_axes = None  # device axes; cached like the reference's fine_grid
         self._fine_grid = None
         self.center_grid = None
 
@@ -241,7 +243,8 @@ class ProjectLayerWithMask(nn.Module):
         live = None
         if grid_center.shape[1] != 3:
             live = (grid_center[:, 3] >= 0).to(torch.uint8).contiguous()
-        cam = pack_cameras(centers, scales, cameras, self.image_size).to(device)
+        cam = pack_cameras(centers, scales, cameras, self.image_size,
+                           self.mm_mode).to(device)
         tl, st, en = (t.to(torch.int32).contiguous() for t in (centers_tl, start, end))
         cubes = torch.empty(B, C, *self._sub_cube, dtype=torch.float32, device=device)
         for c0, cs in _Slices(C).items:

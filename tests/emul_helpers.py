@@ -28,14 +28,14 @@ def padded(c):
     return max(cp, 16)
 
 
-def run_root(emul, case):
+def run_root(emul, case, mm_mode='auto'):
     fms, grid_size, grid_center, cube_size, centers, scales, cameras = case['args']
     B, C, H, W = fms[0].shape
     V = len(fms)
     layer = PL.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
     live = layer._live(grid_center, B, 'cpu')
     axes, cube = layer._axes(grid_size, grid_center, cube_size, B, 'cpu')
-    cam = pack_cameras(centers, scales, cameras, layer.image_size).numpy()
+    cam = pack_cameras(centers, scales, cameras, layer.image_size, mm_mode).numpy()
     cp = padded(C)
     hm = nhwc(fms, cp).numpy()
     X, Y, Z = cube
@@ -55,7 +55,7 @@ def run_root(emul, case):
     return cubes.reshape(B, C, X, Y, Z), mask
 
 
-def run_window(emul, case):
+def run_window(emul, case, mm_mode='auto'):
     (fms, grid_center, space_center, space_size, sub_space, sub_cube, centers, scales,
      cameras) = case['args']
     B, C, H, W = fms[0].shape
@@ -65,7 +65,7 @@ def run_window(emul, case):
     tl, offset, st, en = layer.window_geometry(grid_center)
     layer._ensure_grids('cpu')
     live = (grid_center[:, 3] >= 0).to(torch.uint8).numpy()
-    cam = pack_cameras(centers, scales, cameras, layer.image_size).numpy()
+    cam = pack_cameras(centers, scales, cameras, layer.image_size, mm_mode).numpy()
     cp = padded(C)
     hm = nhwc(fms, cp).numpy()
     fa = [np.ascontiguousarray(a.numpy()) for a in layer._fine_axes]

@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 import cases  # noqa: E402
 from oracle import project_layer_ref as O  # noqa: E402
+from tempo_amd import numerics  # noqa: E402
 
 
 def digest(tensors):
@@ -55,13 +56,18 @@ def run_window(name):
 
 def main():
     torch.manual_seed(0)
+    # the K=3 matmuls of the oracle go through this host's BLAS: record which
+    # rounding flavour produced the files (tempo_amd/numerics.py)
+    mm = numerics.probe()
+    flavour = np.array([mm[s] for s in numerics.SITES])
+    print('matmul flavour on this host:', mm)
     for name in cases.ROOT_CASES:
         out = run_root(name)
-        np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+        np.savez_compressed(os.path.join(HERE, name + '.npz'), mm_mode=flavour, **out)
         print(name, out['cubes'].shape, float(out['cubes'].mean()))
     for name in cases.WINDOW_CASES:
         out = run_window(name)
-        np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+        np.savez_compressed(os.path.join(HERE, name + '.npz'), mm_mode=flavour, **out)
         print(name, out['cubes'].shape, float(out['cubes'].mean()))
 
 
