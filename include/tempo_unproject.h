@@ -23,14 +23,17 @@
  *   [9..11]  T_w2c = -(T^T @ R)
  *   [12..17] K[0][0..2], K[1][0..2]        (pixel = [x y 1] @ K^T)
  *   [18..20] radial k0 k1 k2   [21..22] tangential p0 p1
- *   [23]     flags as a float: 1 = distortion terms apply; 2 / 4 / 8 = evaluate
- *            X @ R / [x y 1] @ K^T / affine @ [x y 1]^T as three products and
- *            two adds instead of multiply + two FMAs (the host BLAS flavour,
- *            see tempo_amd/numerics.py)
+ *   [23]     != 0 when the distortion terms apply
  *   [24..29] 2x3 image affine (mmpose get_affine_transform(center, scale/200, 0, image_size))
  *   [30] width = center[0]*2   [31] height = center[1]*2
  * (what the reference rebuilds per (batch, view) at project_layer.py:97-110 and
  *  :240-254 through mmpose's SimpleCameraTorch / get_affine_transform.)
+ *
+ * mm_unfused: rounding flavour of the path's three K=3 matmuls (X @ R,
+ * [x y 1] @ K^T, affine @ [x y 1]^T), which the reference runs through the
+ * host BLAS: 0 = multiply + two FMAs ascending in k (oneMKL on Intel),
+ * TEMPO_MM_UNFUSED = three products and two adds ascending in k (oneMKL on AMD
+ * EPYC).  tempo_amd/numerics.py measures the host and picks the matching one.
  */
 #ifndef TEMPO_UNPROJECT_H
 #define TEMPO_UNPROJECT_H
@@ -45,6 +48,8 @@ extern "C" {
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
+#define TEMPO_MM_FMA 0
+#define TEMPO_MM_UNFUSED 7
 
 enum {
   TEMPO_OK = 0,
@@ -95,7 +100,8 @@ int tempo_unproject_root(const float* hm, const float* cam, const float* ax_x,
                          const uint8_t* live, float* cubes, float* grids,
                          void* mask, int mask_bytes, int B, int V, int C,
                          int CP, int H, int W, int X, int Y, int Z, float hm_w,
-                         float hm_h, float img_w, float img_h, void* stream);
+                         float hm_h, float img_w, float img_h, int mm_unfused,
+                         void* stream);
 
 /* Per-person window unprojection: ProjectLayerWithMask.get_voxel +
  * project_grid, project_layer.py:225-378 (agg_method == 'mean').  Only the
@@ -116,7 +122,8 @@ int tempo_unproject_window(const float* hm, const float* cam,
                            const uint8_t* live, float* cubes, int NW, int F,
                            int V, int C, int CP, int H, int W, int FX, int FY,
                            int FZ, int VX, int VY, int VZ, float hm_w,
-                           float hm_h, float img_w, float img_h, void* stream);
+                           float hm_h, float img_w, float img_h, int mm_unfused,
+                           void* stream);
 
 /* Projection only, for parity checks of the coordinate chain
  * (SimpleCameraTorch.world_to_pixel + project_layer.py:113-126):
@@ -124,7 +131,8 @@ int tempo_unproject_window(const float* hm, const float* cam,
  *   grid [M,N,2] grid_sample coordinates, inside [M,N] bytes (bounds test). */
 int tempo_project_points(const float* pts, const float* cam, int M, int N,
                          float hm_w, float hm_h, float img_w, float img_h,
-                         float* pix, float* grid, uint8_t* inside, void* stream);
+                         int mm_unfused, float* pix, float* grid, uint8_t* inside,
+                         void* stream);
 
 #ifdef __cplusplus
 }

@@ -21,11 +21,11 @@ SIGNATURES = {
     'tempo_repack_nhwc': (_c_int, [ctypes.POINTER(_c_void_p)] + [_c_int] * 8 +
                           [_c_void_p, _c_void_p]),
     'tempo_unproject_root': (_c_int, [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 4 +
-                             [_c_int] * 10 + [_c_float] * 4 + [_c_void_p]),
+                             [_c_int] * 10 + [_c_float] * 4 + [_c_int, _c_void_p]),
     'tempo_unproject_window': (_c_int, [_c_void_p] * 11 + [_c_int] * 13 +
-                               [_c_float] * 4 + [_c_void_p]),
+                               [_c_float] * 4 + [_c_int, _c_void_p]),
     'tempo_project_points': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int] +
-                             [_c_float] * 4 + [_c_void_p] * 4),
+                             [_c_float] * 4 + [_c_int] + [_c_void_p] * 4),
 }
 
 _lib = None

@@ -20,7 +20,7 @@ import torch
 
 from . import numerics
 
-CAM_R, CAM_T, CAM_K, CAM_KD, CAM_PD, CAM_FLAGS, CAM_TRANS = 0, 9, 12, 18, 21, 23, 24
+CAM_R, CAM_T, CAM_K, CAM_KD, CAM_PD, CAM_HASD, CAM_TRANS = 0, 9, 12, 18, 21, 23, 24
 CAM_WIDTH, CAM_HEIGHT, CAM_FLOATS = 30, 31, 32
 
 
@@ -123,13 +123,14 @@ def _camera_record(param, out, mm_mode='auto'):
         # branch tests ``k.size == 6`` on a tensor and never runs)
         out[CAM_KD:CAM_KD + 3] = torch.from_numpy(k[:3].copy())
         out[CAM_PD:CAM_PD + 2] = torch.from_numpy(p.copy())
-        out[CAM_FLAGS] += float(numerics.F_DIST)
+        out[CAM_HASD] = 1.0
 
 
 def pack_cameras(centers, scales, cameras, image_size, mm_mode='auto'):
     """``centers[b][v]``, ``scales[b][v]`` (np.float32 (2,)), ``cameras[b][v]``
-    (dict) -> CPU fp32 tensor ``[B,V,32]``.  ``mm_mode``: rounding flavour of
-    the K=3 matmuls, see ``tempo_amd.numerics`` (default: as torch on this host)."""
+    (dict) -> CPU fp32 tensor ``[B,V,32]``.  ``mm_mode``: rounding flavour used
+    for ``T_w2c = -(T^T @ R)``, see ``tempo_amd.numerics`` (default: the torch
+    op itself, i.e. as the reference on this host)."""
     B = len(cameras)
     V = len(cameras[0])
     table = torch.zeros(B, V, CAM_FLOATS, dtype=torch.float32)
@@ -159,5 +160,4 @@ def pack_cameras(centers, scales, cameras, image_size, mm_mode='auto'):
     wh = torch.from_numpy(cen * 2)  # width, height = center * 2 (float32)
     flat[:, CAM_WIDTH] = wh[:, 0]
     flat[:, CAM_HEIGHT] = wh[:, 1]
-    flat[:, CAM_FLAGS] += float(numerics.flag_bits(mm_mode))
     return table

@@ -6,18 +6,21 @@
 // See include/tempo_unproject.h for the ABI and DESIGN.md for the layout and
 // the roofline reasoning.  No MFMA: the path is a gather + streaming store.
 //
-// Kernel structure (one 256-thread workgroup = one tile of TILE consecutive
-// voxels of one batch item / window):
-//   phase A  one lane per (voxel, view): project, distort, bounds-test, turn the
-//            sample point into 4 texel byte-offsets + 4 bilinear weights, park
-//            them in LDS.  The camera record is wave-uniform -> scalar loads.
-//   phase B  L lanes per voxel, lane cq owns channels 4cq..4cq+3: for every
-//            view one 16-byte buffer_load per texel (L lanes read one texel's
-//            CP*4 contiguous bytes), texels outside the map / views failing
-//            the bounds test use an out-of-range offset, which the buffer
-//            hardware answers with 0 and no memory traffic; bilinear mix and
-//            the view sum run in registers in torch's summation order.
-//   phase C  normalise, clamp, transpose through LDS, store TILE*4 contiguous
+// Kernel structure.  One wave = 64 consecutive voxels of one batch item / window
+// and is autonomous (no workgroup barrier; a 256-thread workgroup is four such
+// waves sharing an LDS allocation):
+//   phase A  lane = voxel.  For each view of the current group (VU views): the
+//            camera record comes in through scalar loads (wave-uniform), the
+//            lane projects, distorts, bounds-tests and turns the sample point
+//            into 4 texel byte-offsets + 4 bilinear weights, parked in LDS.
+//   phase B  L lanes per voxel (lane cq owns channels 4cq..4cq+3), 64/L voxels
+//            per sub-step: per view one 16-byte buffer_load per texel, so L
+//            lanes read one texel's CP*4 contiguous bytes; texels outside the
+//            map and views failing the bounds test carry an out-of-range
+//            offset, which the buffer hardware answers with 0 and no memory
+//            traffic.  Bilinear mix and the view sum run in registers in
+//            torch's summation order.
+//   phase C  normalise, clamp, transpose through LDS, store 256 contiguous
 //            bytes per channel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -28,11 +31,13 @@
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kWaveVox = 64;                // voxels per wave
 constexpr unsigned kInvalid = 0x80000000u;  // >= any view's byte size (host-checked)
 constexpr int MODE_ROOT = 0;
 constexpr int MODE_WINDOW = 1;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define TEMPO_AS4 __attribute__((address_space(4)))
 
 struct UnprojArgs {
   const float* hm;
@@ -51,17 +56,34 @@ struct UnprojArgs {
   unsigned view_bytes;     // H*W*CP*4
   int NB;                  // batch items (root) / windows
   int V, C, CP, H, W;
-  int dim[3];  // output voxels per axis
-  int fdim[3]; // window: extent of the fine axes
-  int F;       // frames in hm / cam
-  int N;       // dim[0]*dim[1]*dim[2]
-  int tiles;   // tiles per batch item
-  int total;   // NB * tiles
-  int chunk;   // ceil(total / 8): contiguous run of work items per XCD label
+  int dim[3];   // output voxels per axis
+  int fdim[3];  // window: extent of the fine axes
+  int F;        // frames in hm / cam
+  int N;        // dim[0]*dim[1]*dim[2]
+  int tiles;    // tiles (one per workgroup) per batch item
+  int tile_vox; // voxels per tile = 64 * waves per workgroup
+  int total;    // NB * tiles
+  int chunk;    // ceil(total / 8): contiguous run of work items per XCD label
   int mask_bytes;
   int n_slots;  // view slots, padded to a multiple of VU
   float hm_w, hm_h, img_w, img_h;
 };
+
+// wave-uniform read through the scalar data cache (constant address space)
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T* p, long long i) {
+  const T TEMPO_AS4* q = (const T TEMPO_AS4*)(uintptr_t)(p + i);
+  return *q;
+}
+
+__device__ __forceinline__ TempoCam load_cam(const float* cam, long long rec) {
+  const float TEMPO_AS4* q = (const float TEMPO_AS4*)(uintptr_t)(cam + rec * CAM_FLOATS);
+  TempoCam c;
+  float* d = reinterpret_cast<float*>(&c);
+#pragma unroll
+  for (int i = 0; i < CAM_FLOATS; i++) d[i] = q[i];
+  return c;
+}
 
 template <int MODE>
 __device__ __forceinline__ bool voxel_world(const UnprojArgs& a, int b, int n,
@@ -76,14 +98,15 @@ __device__ __forceinline__ bool voxel_world(const UnprojArgs& a, int b, int n,
     *z = a.ax[2][b * a.ax_stride[2] + i2];
     return true;
   } else {
-    const int f0 = a.tl[3 * b + 0] + i0;
-    const int f1 = a.tl[3 * b + 1] + i1;
-    const int f2 = a.tl[3 * b + 2] + i2;
-    const bool act = f0 >= a.start[3 * b + 0] && f0 < a.end[3 * b + 0] &&
-                     f1 >= a.start[3 * b + 1] && f1 < a.end[3 * b + 1] &&
-                     f2 >= a.start[3 * b + 2] && f2 < a.end[3 * b + 2] &&
-                     (unsigned)f0 < (unsigned)a.fdim[0] &&  // never read past an axis
-                     (unsigned)f1 < (unsigned)a.fdim[1] && (unsigned)f2 < (unsigned)a.fdim[2];
+    const int f0 = uniform_load(a.tl, 3 * b + 0) + i0;
+    const int f1 = uniform_load(a.tl, 3 * b + 1) + i1;
+    const int f2 = uniform_load(a.tl, 3 * b + 2) + i2;
+    const bool act =
+        f0 >= uniform_load(a.start, 3 * b + 0) && f0 < uniform_load(a.end, 3 * b + 0) &&
+        f1 >= uniform_load(a.start, 3 * b + 1) && f1 < uniform_load(a.end, 3 * b + 1) &&
+        f2 >= uniform_load(a.start, 3 * b + 2) && f2 < uniform_load(a.end, 3 * b + 2) &&
+        (unsigned)f0 < (unsigned)a.fdim[0] &&  // never read past an axis
+        (unsigned)f1 < (unsigned)a.fdim[1] && (unsigned)f2 < (unsigned)a.fdim[2];
     if (!act) return false;
     *x = a.ax[0][f0];
     *y = a.ax[1][f1];
@@ -92,16 +115,11 @@ __device__ __forceinline__ bool voxel_world(const UnprojArgs& a, int b, int n,
   }
 }
 
-template <int MODE, int L, int VU>
+template <int MODE, int L, int VU, int UNF>
 __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a) {
-  constexpr int VPW = 64 / L;      // voxels per wave in phase B
-  constexpr int TILE = 4 * VPW;    // voxels per workgroup
-  constexpr int NCH = (TILE + 63) / 64;
-  constexpr int TSTR = TILE + 4;   // row stride of the output staging tile
+  constexpr int VPS = 64 / L;                       // voxels per sub-step of phase B
+  constexpr int NSUB = (kWaveVox + VPS - 1) / VPS;  // sub-steps per wave
   extern __shared__ __align__(16) unsigned char smem[];
-  u32x4* s_off = reinterpret_cast<u32x4*>(smem);
-  float4* s_wt = reinterpret_cast<float4*>(smem + (size_t)a.n_slots * TILE * 16);
-  float* s_out = reinterpret_cast<float*>(smem);
 
   // XCD-aware work order: workgroups b, b+8, b+16.. share an XCD (and its L2);
   // give each such group one contiguous run of (batch item, tile) pairs so an
@@ -111,23 +129,26 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
   const int item = (bid & 7) * a.chunk + run;
   if (run >= a.chunk || item >= a.total) return;
   const int b = item / a.tiles;
-  const int n0 = (item - b * a.tiles) * TILE;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = (item - b * a.tiles) * a.tile_vox + wave * kWaveVox;  // wave's first voxel
+  if (n0 >= a.N) return;
   const int CPB = a.CP * 4;
 
+  // wave-private LDS: n_slots x 64 records of (4 texel offsets, 4 weights)
+  unsigned char* wbase = smem + (size_t)wave * a.n_slots * kWaveVox * 32;
+  u32x4* s_off = reinterpret_cast<u32x4*>(wbase);
+  float4* s_wt = reinterpret_cast<float4*>(wbase + (size_t)a.n_slots * kWaveVox * 16);
+
   int frame = b;
-  if (MODE == MODE_WINDOW && a.win_frame != nullptr) frame = a.win_frame[b];
-  const bool dead = (a.live != nullptr && a.live[b] == 0) || (unsigned)frame >= (unsigned)a.F;
+  if (MODE == MODE_WINDOW && a.win_frame != nullptr) frame = uniform_load(a.win_frame, b);
+  const bool dead = (a.live != nullptr && uniform_load(a.live, b) == 0) ||
+                    (unsigned)frame >= (unsigned)a.F;
+  const int n = n0 + lane;  // phase A: this lane's voxel
   if (dead) {
-    for (int i = tid; i < a.C * TILE; i += kThreads) {
-      const int ch = i / TILE, n = n0 + (i - ch * TILE);
-      if (n < a.N) a.cubes[((long long)b * a.C + ch) * a.N + n] = 0.0f;
-    }
-    for (int i = tid; i < TILE; i += kThreads) {
-      const int n = n0 + i;
-      if (n >= a.N) continue;
+    if (n < a.N) {
+      for (int ch = 0; ch < a.C; ch++) a.cubes[((long long)b * a.C + ch) * a.N + n] = 0.0f;
       if (a.grids != nullptr) {
         float* g = a.grids + ((long long)b * a.N + n) * 3;
         g[0] = g[1] = g[2] = 0.0f;
@@ -141,123 +162,122 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
   }
 
   // ---------------------------------------------------------------- phase A
-  for (int wi = wave; wi < a.n_slots * NCH; wi += 4) {
-    const int slot = wi / NCH;
-    const int vox = (wi - slot * NCH) * 64 + lane;
-    const int view = tempo_view_of_slot(slot, a.V);
-    if (vox >= TILE) continue;
-    u32x4 off = {kInvalid, kInvalid, kInvalid, kInvalid};
-    float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int n = n0 + vox;
-    float x, y, z;
-    if (view >= 0 && n < a.N && voxel_world<MODE>(a, b, n, &x, &y, &z)) {
-      const float* cam = a.cam + ((long long)frame * a.V + view) * CAM_FLOATS;
-      const TempoPix p = tempo_world_to_pixel(cam, x, y, z);
-      float gx, gy;
-      tempo_pixel_to_grid(cam, p.px, p.py, a.hm_w, a.hm_h, a.img_w, a.img_h, &gx, &gy);
-      const TempoTap t = tempo_bilinear_tap(gx, gy, a.W, a.H);
-      // root: a view that fails the bounds test is multiplied by 0 in the
-      // reference; skip its texels unless the coordinates are NaN (then the
-      // reference's 0 * NaN poisons the voxel and so must we).
-      const bool skip = (MODE == MODE_ROOT) && !p.inside && gx == gx && gy == gy;
-      const bool x0ok = (unsigned)t.x0 < (unsigned)a.W;
-      const bool x1ok = (unsigned)(t.x0 + 1) < (unsigned)a.W;
-      const bool y0ok = (unsigned)t.y0 < (unsigned)a.H;
-      const bool y1ok = (unsigned)(t.y0 + 1) < (unsigned)a.H;
-      const unsigned base = (unsigned)((t.y0 * a.W + t.x0) * CPB);
-      const unsigned row = (unsigned)(a.W * CPB);
-      if (!skip) {
-        off.x = (x0ok && y0ok) ? base : kInvalid;
-        off.y = (x1ok && y0ok) ? base + CPB : kInvalid;
-        off.z = (x0ok && y1ok) ? base + row : kInvalid;
-        off.w = (x1ok && y1ok) ? base + row + CPB : kInvalid;
-      }
-      if (MODE == MODE_ROOT) off.x |= (unsigned)p.inside;  // bit 0 rides along
-      wt = make_float4(t.nw, t.ne, t.sw, t.se);
+  {
+    float x = 0.f, y = 0.f, z = 0.f;
+    const bool have = n < a.N && voxel_world<MODE>(a, b, n, &x, &y, &z);
+    if (MODE == MODE_ROOT && a.grids != nullptr && have) {
+      float* g = a.grids + ((long long)b * a.N + n) * 3;
+      g[0] = x;
+      g[1] = y;
+      g[2] = z;
     }
-    s_off[slot * TILE + vox] = off;
-    s_wt[slot * TILE + vox] = wt;
-  }
-  if (MODE == MODE_ROOT && a.grids != nullptr) {
-    for (int i = tid; i < TILE; i += kThreads) {
-      const int n = n0 + i;
-      float x, y, z;
-      if (n < a.N && voxel_world<MODE>(a, b, n, &x, &y, &z)) {
-        float* g = a.grids + ((long long)b * a.N + n) * 3;
-        g[0] = x;
-        g[1] = y;
-        g[2] = z;
+#pragma unroll 1
+    for (int slot = 0; slot < a.n_slots; slot++) {
+      const int view = tempo_view_of_slot(slot, a.V);
+      u32x4 off = {kInvalid, kInvalid, kInvalid, kInvalid};
+      float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (view >= 0) {  // wave-uniform
+        const TempoCam cam = load_cam(a.cam, (long long)frame * a.V + view);
+        if (have) {
+          const TempoPix p = tempo_world_to_pixel(&cam, x, y, z, UNF);
+          float gx, gy;
+          tempo_pixel_to_grid(&cam, p.px, p.py, a.hm_w, a.hm_h, a.img_w, a.img_h, UNF, &gx,
+                              &gy);
+          const TempoTap t = tempo_bilinear_tap(gx, gy, a.W, a.H);
+          // root: a view that fails the bounds test is multiplied by 0 in the
+          // reference; skip its texels unless the coordinates are NaN (then the
+          // reference's 0 * NaN poisons the voxel and so must we).
+          const bool skip = (MODE == MODE_ROOT) && !p.inside && gx == gx && gy == gy;
+          const bool x0ok = (unsigned)t.x0 < (unsigned)a.W;
+          const bool x1ok = (unsigned)(t.x0 + 1) < (unsigned)a.W;
+          const bool y0ok = (unsigned)t.y0 < (unsigned)a.H && !skip;
+          const bool y1ok = (unsigned)(t.y0 + 1) < (unsigned)a.H && !skip;
+          const unsigned base = (unsigned)((t.y0 * a.W + t.x0) * CPB);
+          const unsigned row = (unsigned)(a.W * CPB);
+          off.x = (x0ok && y0ok) ? base : kInvalid;
+          off.y = (x1ok && y0ok) ? base + CPB : kInvalid;
+          off.z = (x0ok && y1ok) ? base + row : kInvalid;
+          off.w = (x1ok && y1ok) ? base + row + CPB : kInvalid;
+          if (MODE == MODE_ROOT) off.x |= (unsigned)p.inside;  // bit 0 rides along
+          wt = make_float4(t.nw, t.ne, t.sw, t.se);
+        }
       }
+      s_off[slot * kWaveVox + lane] = off;
+      s_wt[slot * kWaveVox + lane] = wt;
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   // ---------------------------------------------------------------- phase B
-  const bool lane_on = lane < VPW * L;
+  const bool lane_on = lane < VPS * L;
   const int vq = lane / L;
   const int cq = lane - vq * L;
-  const int vsl = lane_on ? wave * VPW + vq : 0;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  int cnt = 0;
-  unsigned mbits = 0;
+  const unsigned lo = (unsigned)cq * 16u;
   const char* fbase = reinterpret_cast<const char*>(a.hm + (long long)frame * a.frame_stride);
-  for (int s0 = 0; s0 < a.n_slots; s0 += VU) {
-    u32x4 o[VU];
-    float4 w[VU];
-    u32x4 tex[VU][4];
+#pragma unroll 1
+  for (int s = 0; s < NSUB; s++) {
+    const int vsl = s * VPS + vq;
+    const bool on = lane_on && vsl < kWaveVox && n0 + vsl < a.N;
+    const int rd = on ? vsl : 0;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int cnt = 0;
+    unsigned mbits = 0;
+#pragma unroll 1
+    for (int g0 = 0; g0 < a.n_slots; g0 += VU) {
+      u32x4 o[VU];
+      float4 w[VU];
+      u32x4 tex[VU][4];
 #pragma unroll
-    for (int u = 0; u < VU; u++) {
-      o[u] = s_off[(s0 + u) * TILE + vsl];
-      w[u] = s_wt[(s0 + u) * TILE + vsl];
-    }
+      for (int u = 0; u < VU; u++) {
+        o[u] = s_off[(g0 + u) * kWaveVox + rd];
+        w[u] = s_wt[(g0 + u) * kWaveVox + rd];
+      }
 #pragma unroll
-    for (int u = 0; u < VU; u++) {
-      const int view = tempo_view_of_slot(s0 + u, a.V);
-      const char* vbase = fbase + (long long)(view < 0 ? 0 : view) * a.view_bytes;
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char*>(vbase), 0, (int)a.view_bytes, 0x00020000);
-      const unsigned lo = (unsigned)cq * 16u;
-      tex[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (o[u].x & ~15u) + lo, 0, 0);
-      tex[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].y + lo, 0, 0);
-      tex[u][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].z + lo, 0, 0);
-      tex[u][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].w + lo, 0, 0);
-    }
+      for (int u = 0; u < VU; u++) {
+        const int view = tempo_view_of_slot(g0 + u, a.V);
+        const char* vbase = fbase + (long long)(view < 0 ? 0 : view) * a.view_bytes;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(vbase), 0, (int)a.view_bytes, 0x00020000);
+        tex[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (o[u].x & ~15u) + lo, 0, 0);
+        tex[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].y + lo, 0, 0);
+        tex[u][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].z + lo, 0, 0);
+        tex[u][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].w + lo, 0, 0);
+      }
 #pragma unroll
-    for (int u = 0; u < VU; u++) {
-      const int view = tempo_view_of_slot(s0 + u, a.V);
-      const unsigned in = o[u].x & 1u;
-      cnt += (int)in;
-      if (view >= 0) mbits |= in << view;
+      for (int u = 0; u < VU; u++) {
+        const int view = tempo_view_of_slot(g0 + u, a.V);
+        const unsigned in = o[u].x & 1u;
+        cnt += (int)in;
+        if (view >= 0) mbits |= in << view;
 #pragma unroll
-      for (int c = 0; c < 4; c++) {
-        const float s = tempo_bilinear_mix(
-            __uint_as_float(tex[u][0][c]), __uint_as_float(tex[u][1][c]),
-            __uint_as_float(tex[u][2][c]), __uint_as_float(tex[u][3][c]), w[u].x,
-            w[u].y, w[u].z, w[u].w);
-        acc[c] = acc[c] + s;
+        for (int c = 0; c < 4; c++) {
+          const float v = tempo_bilinear_mix(
+              __uint_as_float(tex[u][0][c]), __uint_as_float(tex[u][1][c]),
+              __uint_as_float(tex[u][2][c]), __uint_as_float(tex[u][3][c]), w[u].x,
+              w[u].y, w[u].z, w[u].w);
+          acc[c] = acc[c] + v;
+        }
       }
     }
-  }
-  __syncthreads();  // every wave is done reading s_off / s_wt; s_out aliases them
-
-  // ---------------------------------------------------------------- phase C
-  const float den = (MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f;
-  if (lane_on) {
+    // -------------------------------------------------------------- phase C
+    // 64/L consecutive voxels x 4 channels per store instruction: runs of
+    // (64/L)*4 bytes per channel plane, merged to full lines in L2
+    if (on) {
+      const float den = (MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f;
+      float* dst = a.cubes + ((long long)b * a.C + 4 * cq) * a.N + n0 + vsl;
 #pragma unroll
-    for (int c = 0; c < 4; c++)
-      s_out[(4 * cq + c) * TSTR + vsl] = tempo_nan_clamp(acc[c] / den, 0.0f, 1.0f);
-    if (MODE == MODE_ROOT && a.mask != nullptr && cq == 0 && n0 + vsl < a.N) {
-      char* m = (char*)a.mask + ((long long)b * a.N + n0 + vsl) * a.mask_bytes;
-      if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mbits;
-      else if (a.mask_bytes == 2) *(uint16_t*)m = (uint16_t)mbits;
-      else *(uint32_t*)m = mbits;
+      for (int c = 0; c < 4; c++)
+        if (4 * cq + c < a.C)
+          dst[(long long)c * a.N] = tempo_nan_clamp(acc[c] / den, 0.0f, 1.0f);
+      if (MODE == MODE_ROOT && a.mask != nullptr && cq == 0) {
+        char* m = (char*)a.mask + ((long long)b * a.N + n0 + vsl) * a.mask_bytes;
+        if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mbits;
+        else if (a.mask_bytes == 2) *(uint16_t*)m = (uint16_t)mbits;
+        else *(uint32_t*)m = mbits;
+      }
     }
-  }
-  __syncthreads();
-  for (int i = tid; i < a.C * TILE; i += kThreads) {
-    const int ch = i / TILE, vox = i - ch * TILE;
-    const int n = n0 + vox;
-    if (n < a.N) a.cubes[((long long)b * a.C + ch) * a.N + n] = s_out[ch * TSTR + vox];
   }
 }
 
@@ -296,15 +316,16 @@ __global__ __launch_bounds__(kThreads) void repack_kernel(const RepackArgs a) {
 // ---------------------------------------------------------- project points
 __global__ __launch_bounds__(kThreads) void project_points_kernel(
     const float* __restrict__ pts, const float* __restrict__ cam, int N, float hm_w,
-    float hm_h, float img_w, float img_h, float* __restrict__ pix,
+    float hm_h, float img_w, float img_h, int unfused, float* __restrict__ pix,
     float* __restrict__ grid, uint8_t* __restrict__ inside) {
   const int m = blockIdx.y;
   const int n = blockIdx.x * kThreads + threadIdx.x;
   if (n >= N) return;
-  const float* c = cam + (long long)m * CAM_FLOATS;
-  const TempoPix p = tempo_world_to_pixel(c, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2]);
+  const TempoCam c = load_cam(cam, m);
+  const TempoPix p =
+      tempo_world_to_pixel(&c, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], unfused);
   float gx, gy;
-  tempo_pixel_to_grid(c, p.px, p.py, hm_w, hm_h, img_w, img_h, &gx, &gy);
+  tempo_pixel_to_grid(&c, p.px, p.py, hm_w, hm_h, img_w, img_h, unfused, &gx, &gy);
   const long long o = (long long)m * N + n;
   pix[2 * o] = p.px;
   pix[2 * o + 1] = p.py;
@@ -314,43 +335,54 @@ __global__ __launch_bounds__(kThreads) void project_points_kernel(
 }
 
 // ------------------------------------------------------------ host helpers
-template <int MODE, int L, int VU>
+template <int MODE, int L, int VU, int UNF>
 int launch_one(const UnprojArgs& a, hipStream_t stream) {
-  constexpr int TILE = 4 * (64 / L);
   UnprojArgs k = a;
-  k.tiles = (a.N + TILE - 1) / TILE;
+  k.n_slots = ((a.V + VU - 1) / VU) * VU;
+  // wave-private LDS holds every view's records; fewer waves per workgroup when
+  // many views would not fit 64 KB
+  const size_t per_wave = (size_t)k.n_slots * kWaveVox * 32;
+  int waves = (int)((64 * 1024) / per_wave);
+  if (waves < 1) return TEMPO_E_DIM;
+  if (waves > kThreads / 64) waves = kThreads / 64;
+  k.tile_vox = waves * kWaveVox;
+  k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
   const long long total = (long long)a.NB * k.tiles;
   if (total > 0x7fffffffLL / 8) return TEMPO_E_DIM;
   k.total = (int)total;
   k.chunk = (k.total + 7) / 8;
-  k.n_slots = ((a.V + VU - 1) / VU) * VU;
-  size_t lds = (size_t)k.n_slots * TILE * 32;
-  const size_t lds_out = (size_t)a.CP * (TILE + 4) * 4;
-  if (lds_out > lds) lds = lds_out;
-  if (lds > 64 * 1024) return TEMPO_E_DIM;
-  hipLaunchKernelGGL((unproject_kernel<MODE, L, VU>), dim3(8 * k.chunk), dim3(kThreads),
-                     lds, stream, k);
+  hipLaunchKernelGGL((unproject_kernel<MODE, L, VU, UNF>), dim3(8 * k.chunk),
+                     dim3(waves * 64), per_wave * waves, stream, k);
   return (int)hipGetLastError();
 }
 
-template <int MODE, int L>
+template <int MODE, int L, int UNF>
 int launch_vu(const UnprojArgs& a, hipStream_t stream) {
   // views are gathered VU at a time; pick the unroll that pads V least
   const int pad5 = (5 - a.V % 5) % 5, pad4 = (4 - a.V % 4) % 4;
-  if (pad5 <= pad4) return launch_one<MODE, L, 5>(a, stream);
-  return launch_one<MODE, L, 4>(a, stream);
+  if (pad5 <= pad4) return launch_one<MODE, L, 5, UNF>(a, stream);
+  return launch_one<MODE, L, 4, UNF>(a, stream);
+}
+
+template <int MODE, int UNF>
+int launch_l(const UnprojArgs& a, hipStream_t stream) {
+  switch (a.CP / 4) {
+    case 4: return launch_vu<MODE, 4, UNF>(a, stream);
+    case 5: return launch_vu<MODE, 5, UNF>(a, stream);
+    case 6: return launch_vu<MODE, 6, UNF>(a, stream);
+    case 7: return launch_vu<MODE, 7, UNF>(a, stream);
+    case 8: return launch_vu<MODE, 8, UNF>(a, stream);
+    default: return TEMPO_E_PAD;
+  }
 }
 
 template <int MODE>
-int launch_mode(const UnprojArgs& a, hipStream_t stream) {
-  switch (a.CP / 4) {
-    case 4: return launch_vu<MODE, 4>(a, stream);
-    case 5: return launch_vu<MODE, 5>(a, stream);
-    case 6: return launch_vu<MODE, 6>(a, stream);
-    case 7: return launch_vu<MODE, 7>(a, stream);
-    case 8: return launch_vu<MODE, 8>(a, stream);
-    default: return TEMPO_E_PAD;
-  }
+int launch_mode(const UnprojArgs& a, int mm_unfused, hipStream_t stream) {
+  // the three matmul sites share one flavour on every host measured so far;
+  // mixed flavours are not compiled in
+  if (mm_unfused == 0) return launch_l<MODE, 0>(a, stream);
+  if (mm_unfused == TEMPO_UNFUSED_ALL) return launch_l<MODE, 1>(a, stream);
+  return TEMPO_E_ARG;
 }
 
 int check_common(int V, int C, int CP, int H, int W) {
@@ -411,7 +443,7 @@ int tempo_unproject_root(const float* hm, const float* cam, const float* ax_x,
                          const uint8_t* live, float* cubes, float* grids, void* mask,
                          int mask_bytes, int B, int V, int C, int CP, int H, int W, int X,
                          int Y, int Z, float hm_w, float hm_h, float img_w, float img_h,
-                         void* stream) {
+                         int mm_unfused, void* stream) {
   if (!hm || !cam || !ax_x || !ax_y || !ax_z || !cubes) return TEMPO_E_NULL;
   const int rc = check_common(V, C, CP, H, W);
   if (rc != TEMPO_OK) return rc;
@@ -435,7 +467,7 @@ int tempo_unproject_root(const float* hm, const float* cam, const float* ax_x,
   a.NB = B; a.F = B; a.V = V; a.C = C; a.CP = CP; a.H = H; a.W = W;
   a.dim[0] = X; a.dim[1] = Y; a.dim[2] = Z; a.N = (int)N;
   a.hm_w = hm_w; a.hm_h = hm_h; a.img_w = img_w; a.img_h = img_h;
-  return launch_mode<MODE_ROOT>(a, (hipStream_t)stream);
+  return launch_mode<MODE_ROOT>(a, mm_unfused, (hipStream_t)stream);
 }
 
 int tempo_unproject_window(const float* hm, const float* cam, const int32_t* win_frame,
@@ -444,7 +476,7 @@ int tempo_unproject_window(const float* hm, const float* cam, const int32_t* win
                            const uint8_t* live, float* cubes, int NW, int F, int V, int C,
                            int CP, int H, int W, int FX, int FY, int FZ, int VX, int VY,
                            int VZ, float hm_w, float hm_h, float img_w, float img_h,
-                           void* stream) {
+                           int mm_unfused, void* stream) {
   if (!hm || !cam || !fx || !fy || !fz || !tl || !start || !end || !cubes)
     return TEMPO_E_NULL;
   const int rc = check_common(V, C, CP, H, W);
@@ -465,17 +497,18 @@ int tempo_unproject_window(const float* hm, const float* cam, const int32_t* win
   a.dim[0] = VX; a.dim[1] = VY; a.dim[2] = VZ; a.N = (int)N;
   a.fdim[0] = FX; a.fdim[1] = FY; a.fdim[2] = FZ;
   a.hm_w = hm_w; a.hm_h = hm_h; a.img_w = img_w; a.img_h = img_h;
-  return launch_mode<MODE_WINDOW>(a, (hipStream_t)stream);
+  return launch_mode<MODE_WINDOW>(a, mm_unfused, (hipStream_t)stream);
 }
 
 int tempo_project_points(const float* pts, const float* cam, int M, int N, float hm_w,
-                         float hm_h, float img_w, float img_h, float* pix, float* grid,
-                         uint8_t* inside, void* stream) {
+                         float hm_h, float img_w, float img_h, int mm_unfused, float* pix,
+                         float* grid, uint8_t* inside, void* stream) {
   if (!pts || !cam || !pix || !grid || !inside) return TEMPO_E_NULL;
   if (M <= 0 || M > 65535 || N <= 0) return TEMPO_E_DIM;
+  if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
   dim3 g((N + kThreads - 1) / kThreads, M);
   hipLaunchKernelGGL(project_points_kernel, g, dim3(kThreads), 0, (hipStream_t)stream, pts,
-                     cam, N, hm_w, hm_h, img_w, img_h, pix, grid, inside);
+                     cam, N, hm_w, hm_h, img_w, img_h, mm_unfused != 0, pix, grid, inside);
   return (int)hipGetLastError();
 }
 

@@ -7,10 +7,10 @@
 // torch's grid_sample unnormalisation).  Element-wise torch ops round after
 // every operation.  The three K=3 matmuls (X @ R, [x y 1] @ K^T, trans @
 // [x y 1]^T) go through the host's BLAS, whose rounding differs between CPUs
-// (probed with torch 2.10 + MKL: an FMA chain ascending in k that starts with
-// a plain multiply on Intel, three products and two adds ascending in k on AMD
-// EPYC), so each site takes a flag that selects the flavour; tempo_amd.numerics
-// probes the host and sets the flags so that the kernels reproduce torch on
+// (probed with torch 2.10 + oneMKL: an FMA chain ascending in k that starts
+// with a plain multiply on Intel, three products and two adds ascending in k
+// on AMD EPYC), so every function takes the flavour as `unfused`;
+// tempo_amd.numerics probes the host so that the kernels reproduce torch on
 // the machine they run on.  The file is compiled with -ffp-contract=off and
 // every fused step is an explicit fmaf(), so neither hipcc nor gcc may
 // re-associate or fuse anything.
@@ -28,28 +28,23 @@
 #define TEMPO_HD static inline
 #endif
 
-// Packed per-(batch item, view) parameter record, 32 floats = 128 B.
-// include/tempo_unproject.h documents the same layout for callers.
-enum {
-  CAM_R = 0,       // 9: R[k][j], row-major, used as X(row) @ R
-  CAM_T = 9,       // 3: T_w2c = -(T^T @ R)
-  CAM_K = 12,      // 6: K[0][0..2], K[1][0..2]  (pix = [x y 1] @ K^T)
-  CAM_KD = 18,     // 3: radial k0 k1 k2
-  CAM_PD = 21,     // 2: tangential p0 p1
-  CAM_FLAGS = 23,  // 1: bit flags stored as a float (TEMPO_F_*)
-  CAM_TRANS = 24,  // 6: 2x3 image affine (get_affine_transform)
-  CAM_WIDTH = 30,  // center[0] * 2
-  CAM_HEIGHT = 31, // center[1] * 2
-  CAM_FLOATS = 32
-};
+// Packed per-(frame, view) parameter record, 32 floats = 128 B; the same
+// layout is documented for callers in include/tempo_unproject.h.
+typedef struct TempoCam {
+  float R[9];      // R[k][j] row-major, used as X(row) @ R
+  float T[3];      // T_w2c = -(T^T @ R)
+  float K[6];      // K[0][0..2], K[1][0..2]  (pix = [x y 1] @ K^T)
+  float kd[3];     // radial k0 k1 k2
+  float pd[2];     // tangential p0 p1
+  float has_dist;  // != 0 when k and p are present
+  float trans[6];  // 2x3 image affine (get_affine_transform)
+  float width;     // center[0] * 2
+  float height;    // center[1] * 2
+} TempoCam;
+enum { CAM_FLOATS = 32 };
 
-// flags in cam[CAM_FLAGS]
-enum {
-  TEMPO_F_DIST = 1,        // k and p present: apply the distortion terms
-  TEMPO_F_UNFUSED_R = 2,   // X @ R        as mul,mul,mul,add,add (else mul,fma,fma)
-  TEMPO_F_UNFUSED_K = 4,   // [x y 1] @ K^T
-  TEMPO_F_UNFUSED_A = 8    // trans @ [x y 1]^T
-};
+// flavour bits of the three matmul sites (argument `mm_unfused` of the ABI)
+enum { TEMPO_UNFUSED_R = 1, TEMPO_UNFUSED_K = 2, TEMPO_UNFUSED_A = 4, TEMPO_UNFUSED_ALL = 7 };
 
 // sum_k a_k * b_k, k ascending, in the flavour the host BLAS uses
 TEMPO_HD float tempo_dot3(float a0, float b0, float a1, float b1, float a2,
@@ -65,31 +60,30 @@ typedef struct TempoPix {
 
 TEMPO_HD float tempo_nan_clamp(float v, float lo, float hi) {
   // torch.clamp: NaN stays NaN
-  if (v != v) return v;
-  v = v < lo ? lo : v;
-  return v > hi ? hi : v;
+  float r = v < lo ? lo : v;
+  r = r > hi ? hi : r;
+  return v != v ? v : r;
 }
 
 // world point -> source-image pixel (SimpleCameraTorch.world_to_pixel)
-TEMPO_HD TempoPix tempo_world_to_pixel(const float* __restrict__ cam, float x,
-                                       float y, float z) {
-  const float* R = cam + CAM_R;
-  const int flags = (int)cam[CAM_FLAGS];
-  const int uf_r = flags & TEMPO_F_UNFUSED_R, uf_k = flags & TEMPO_F_UNFUSED_K;
+TEMPO_HD TempoPix tempo_world_to_pixel(const TempoCam* cam, float x, float y,
+                                       float z, int unfused) {
+  const float* R = cam->R;
   // X @ R_w2c then + T_w2c (separate add)
-  float xc = tempo_dot3(x, R[0], y, R[3], z, R[6], uf_r) + cam[CAM_T + 0];
-  float yc = tempo_dot3(x, R[1], y, R[4], z, R[7], uf_r) + cam[CAM_T + 1];
-  float zc = tempo_dot3(x, R[2], y, R[5], z, R[8], uf_r) + cam[CAM_T + 2];
+  float xc = tempo_dot3(x, R[0], y, R[3], z, R[6], unfused) + cam->T[0];
+  float yc = tempo_dot3(x, R[1], y, R[4], z, R[7], unfused) + cam->T[1];
+  float zc = tempo_dot3(x, R[2], y, R[5], z, R[8], unfused) + cam->T[2];
   // _X = X / X[..., 2:]   (no z > 0 test, as the reference)
   float xn = xc / zc;
   float yn = yc / zc;
-  float zn = zc / zc;
-  if (flags & TEMPO_F_DIST) {
-    const float k0 = cam[CAM_KD], k1 = cam[CAM_KD + 1], k2 = cam[CAM_KD + 2];
-    const float p0 = cam[CAM_PD], p1 = cam[CAM_PD + 1];
+  // zc / zc: 1 for finite non-zero zc, NaN for 0 and +-inf
+  float zn = (zc != 0.0f && zc - zc == 0.0f) ? 1.0f : __builtin_nanf("");
+  if (cam->has_dist != 0.0f) {
+    const float k0 = cam->kd[0], k1 = cam->kd[1], k2 = cam->kd[2];
+    const float p0 = cam->pd[0], p1 = cam->pd[1];
     float r2 = xn * xn + yn * yn;
-    float r4 = r2 * r2;        // r2**2
-    float r6 = r4 * r2;        // r2**3 = (r2*r2)*r2
+    float r4 = r2 * r2;  // r2**2
+    float r6 = r4 * r2;  // r2**3 = (r2*r2)*r2
     float radial = 1.0f + ((k0 * r2 + k1 * r4) + k2 * r6);
     float tang = 2.0f * (p1 * xn + p0 * yn);
     float rt = radial + tang;
@@ -98,30 +92,27 @@ TEMPO_HD TempoPix tempo_world_to_pixel(const float* __restrict__ cam, float x,
     xn = xd;
     yn = yd;
   }
-  const float* K = cam + CAM_K;
+  const float* K = cam->K;
   TempoPix o;
-  o.px = tempo_dot3(xn, K[0], yn, K[1], zn, K[2], uf_k);
-  o.py = tempo_dot3(xn, K[3], yn, K[4], zn, K[5], uf_k);
-  o.inside = (o.px >= 0.0f) & (o.py >= 0.0f) & (o.px < cam[CAM_WIDTH]) &
-             (o.py < cam[CAM_HEIGHT]);
+  o.px = tempo_dot3(xn, K[0], yn, K[1], zn, K[2], unfused);
+  o.py = tempo_dot3(xn, K[3], yn, K[4], zn, K[5], unfused);
+  o.inside = (o.px >= 0.0f) & (o.py >= 0.0f) & (o.px < cam->width) & (o.py < cam->height);
   return o;
 }
 
 // source-image pixel -> grid_sample coordinate in [-1.1, 1.1]
 // (project_layer.py:116-126).  hm_w/hm_h are the module's heatmap_size,
 // img_w/img_h its image_size.
-TEMPO_HD void tempo_pixel_to_grid(const float* __restrict__ cam, float px,
-                                  float py, float hm_w, float hm_h, float img_w,
-                                  float img_h, float* gx, float* gy) {
-  const float wmax = cam[CAM_WIDTH] > cam[CAM_HEIGHT] ? cam[CAM_WIDTH]
-                                                      : cam[CAM_HEIGHT];
+TEMPO_HD void tempo_pixel_to_grid(const TempoCam* cam, float px, float py,
+                                  float hm_w, float hm_h, float img_w, float img_h,
+                                  int unfused, float* gx, float* gy) {
+  const float wmax = cam->width > cam->height ? cam->width : cam->height;
   px = tempo_nan_clamp(px, -1.0f, wmax);
   py = tempo_nan_clamp(py, -1.0f, wmax);
-  const float* t = cam + CAM_TRANS;
+  const float* t = cam->trans;
   // torch.mm(t, [x y 1]^T)
-  const int uf_a = (int)cam[CAM_FLAGS] & TEMPO_F_UNFUSED_A;
-  float ax = tempo_dot3(t[0], px, t[1], py, t[2], 1.0f, uf_a);
-  float ay = tempo_dot3(t[3], px, t[4], py, t[5], 1.0f, uf_a);
+  float ax = tempo_dot3(t[0], px, t[1], py, t[2], 1.0f, unfused);
+  float ay = tempo_dot3(t[3], px, t[4], py, t[5], 1.0f, unfused);
   ax = (ax * hm_w) / img_w;
   ay = (ay * hm_h) / img_h;
   float sx = (ax / (hm_w - 1.0f)) * 2.0f - 1.0f;
@@ -137,14 +128,12 @@ TEMPO_HD float tempo_unnormalize(float g, float size) {
   return fmaf(g + 1.0f, size * 0.5f, -0.5f);
 }
 
-// Bilinear footprint of one sample: top-left texel and the four weights, with
-// the weight of any texel outside [0,W)x[0,H) forced to zero (padding_mode=
-// 'zeros': an outside texel reads as 0, and 0 * w == w' * 0, so zeroing the
-// weight instead of the value is exact).  NaN coordinates give x0 = y0 = 0 and
-// NaN weights, which poison the sample like torch's arithmetic does.
+// Bilinear footprint of one sample: top-left texel and the four weights.
+// NaN coordinates give x0 = y0 = 0 and NaN weights, which poison the sample
+// like torch's arithmetic does (0 * NaN).
 typedef struct TempoTap {
-  int x0, y0;             // top-left texel, may be outside the map
-  float nw, ne, sw, se;   // weights of (x0,y0) (x0+1,y0) (x0,y0+1) (x0+1,y0+1)
+  int x0, y0;            // top-left texel, may be outside the map
+  float nw, ne, sw, se;  // weights of (x0,y0) (x0+1,y0) (x0,y0+1) (x0+1,y0+1)
 } TempoTap;
 
 TEMPO_HD TempoTap tempo_bilinear_tap(float gx, float gy, int W, int H) {
@@ -165,7 +154,8 @@ TEMPO_HD TempoTap tempo_bilinear_tap(float gx, float gy, int W, int H) {
 }
 
 // sample = fma(se_val, se, fma(sw_val, sw, fma(ne_val, ne, nw_val * nw)))
-// (the contraction torch's CPU grid_sample is built with)
+// (the contraction torch's CPU grid_sample is built with); a texel outside the
+// map reads as 0 (padding_mode='zeros')
 TEMPO_HD float tempo_bilinear_mix(float a, float b, float c, float d, float nw,
                                   float ne, float sw, float se) {
   return fmaf(d, se, fmaf(c, sw, fmaf(b, ne, a * nw)));

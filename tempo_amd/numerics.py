@@ -10,8 +10,8 @@ differ between machines in how they round (measured, torch 2.10 + oneMKL 2024.2)
 
 A one-ulp difference in a source-pixel coordinate moves a sample on a
 white-noise heatmap by up to ~1e-4, ten times the parity tolerance, so the
-kernels implement both flavours (csrc/unproject_math.h, ``tempo_dot3``) and the
-packed camera record carries one flag per matmul site.  ``detect()`` measures
+kernels implement both flavours (csrc/unproject_math.h, ``tempo_dot3``) and
+every ABI entry point takes the flavour as ``mm_unfused``.  ``detect()`` measures
 the host once (three small matmuls) so that the HIP result is the one the
 reference's torch ops give on the same machine; ``TEMPO_MM_MODE=fma|unfused``
 pins it instead.
@@ -22,9 +22,8 @@ import warnings
 import numpy as np
 import torch
 
-F_DIST, F_UNFUSED_R, F_UNFUSED_K, F_UNFUSED_A = 1, 2, 4, 8
+MM_FMA, MM_UNFUSED = 0, 7  # TEMPO_MM_* of include/tempo_unproject.h
 SITES = ('R', 'K', 'A')
-_SITE_FLAG = {'R': F_UNFUSED_R, 'K': F_UNFUSED_K, 'A': F_UNFUSED_A}
 _cache = None
 
 
@@ -96,7 +95,13 @@ def resolve(mode):
     return {s: mode[s] for s in SITES}
 
 
-def flag_bits(mode):
-    """Flag bits (without F_DIST) for a mode as accepted by resolve()."""
+def abi_flag(mode):
+    """``mm_unfused`` argument of the C ABI for a mode as accepted by resolve().
+    The kernels are compiled for one flavour across the three sites (what every
+    host measured so far shows); a mixed result falls back to the majority."""
     m = resolve(mode)
-    return sum(_SITE_FLAG[s] for s in SITES if m[s] == 'unfused')
+    n_unf = sum(1 for s in SITES if m[s] == 'unfused')
+    if n_unf not in (0, len(SITES)):
+        warnings.warn(f'tempo_amd.numerics: matmul sites disagree ({m}); using the majority '
+                      'flavour for all three')
+    return MM_UNFUSED if 2 * n_unf > len(SITES) else MM_FMA

@@ -8,7 +8,7 @@ import ctypes
 
 import torch
 
-from . import _lib
+from . import _lib, numerics
 
 
 def _stream_ptr(device):
@@ -68,7 +68,7 @@ def repack_nhwc(feature_maps, c_begin=0, channels=None, out=None):
 
 
 def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
-                   want_grids=False, want_mask=False, out=None):
+                   want_grids=False, want_mask=False, out=None, mm_mode='auto'):
     """Root-grid unprojection on a repacked heatmap tensor.
 
     hm ``[B,V,H,W,CP]``; cam ``[B,V,32]``; axes = (ax_x, ax_y, ax_z), each
@@ -111,13 +111,15 @@ def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
             _ptr(hm), _ptr(cam), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), int(batched),
             _ptr(live), _ptr(out), _ptr(grids), _ptr(mask), mask_bytes, B, V, C, CP, H, W,
             X, Y, Z, float(heatmap_size[0]), float(heatmap_size[1]),
-            float(image_size[0]), float(image_size[1]), _stream_ptr(dev))
+            float(image_size[0]), float(image_size[1]), numerics.abi_flag(mm_mode),
+            _stream_ptr(dev))
     _lib.check(rc, 'tempo_unproject_root')
     return out, grids, mask
 
 
 def unproject_window(hm, cam, fine_axes, tl, start, end, sub_cube, channels,
-                     heatmap_size, image_size, win_frame=None, live=None, out=None):
+                     heatmap_size, image_size, win_frame=None, live=None, out=None,
+                     mm_mode='auto'):
     """Per-person window unprojection.  hm ``[F,V,H,W,CP]``, cam ``[F,V,32]``,
     tl/start/end int32 ``[NW,3]``, win_frame int32 ``[NW]`` or None (NW == F).
     Returns cubes ``[NW,C,VX,VY,VZ]``."""
@@ -158,12 +160,12 @@ def unproject_window(hm, cam, fine_axes, tl, start, end, sub_cube, channels,
             _ptr(tl), _ptr(start), _ptr(end), _ptr(live), _ptr(out), NW, F_, V, C, CP, H,
             W, int(fa[0].numel()), int(fa[1].numel()), int(fa[2].numel()), VX, VY, VZ,
             float(heatmap_size[0]), float(heatmap_size[1]), float(image_size[0]),
-            float(image_size[1]), _stream_ptr(dev))
+            float(image_size[1]), numerics.abi_flag(mm_mode), _stream_ptr(dev))
     _lib.check(rc, 'tempo_unproject_window')
     return out
 
 
-def project_points(pts, cam, heatmap_size, image_size):
+def project_points(pts, cam, heatmap_size, image_size, mm_mode='auto'):
     """pts ``[N,3]``, cam ``[M,32]`` -> (pix ``[M,N,2]``, grid ``[M,N,2]``,
     inside ``[M,N]`` uint8): the coordinate chain alone, for parity checks."""
     lib = _lib.load()
@@ -177,7 +179,7 @@ def project_points(pts, cam, heatmap_size, image_size):
     with torch.cuda.device(dev):
         rc = lib.tempo_project_points(
             _ptr(pts), _ptr(cam), M, N, float(heatmap_size[0]), float(heatmap_size[1]),
-            float(image_size[0]), float(image_size[1]), _ptr(pix), _ptr(grid),
-            _ptr(inside), _stream_ptr(dev))
+            float(image_size[0]), float(image_size[1]), numerics.abi_flag(mm_mode),
+            _ptr(pix), _ptr(grid), _ptr(inside), _stream_ptr(dev))
     _lib.check(rc, 'tempo_project_points')
     return pix, grid, inside

@@ -125,7 +125,7 @@ class ProjectLayer(nn.Module):
                 hm, cam, axes, cs, self.heatmap_size, self.image_size, live=live,
                 want_grids=first and self.materialize_grids,
                 want_mask=first and self.keep_mask,
-                out=cubes if cs == C else None)
+                out=cubes if cs == C else None, mm_mode=self.mm_mode)
             if cs != C:
                 cubes[:, c0:c0 + cs] = out
             if first:
@@ -252,7 +252,7 @@ class ProjectLayerWithMask(nn.Module):
             out = ops.unproject_window(
                 hm, cam, self._fine_axes, tl, st, en, self._sub_cube, cs,
                 self.heatmap_size, self.image_size, live=live,
-                out=cubes if cs == C else None)
+                out=cubes if cs == C else None, mm_mode=self.mm_mode)
             if cs != C:
                 cubes[:, c0:c0 + cs] = out
         return cubes, offset

@@ -6,15 +6,16 @@
 #include "../../tempo_amd/csrc/unproject_math.h"
 
 // pts [n,3] -> pix [n,2], inside [n], grid [n,2]
-void emul_project(const float* cam, const float* pts, long n, float hm_w,
-                  float hm_h, float img_w, float img_h, float* pix, int* inside,
+void emul_project(const float* cam_, const float* pts, long n, float hm_w,
+                  float hm_h, float img_w, float img_h, int unf, float* pix, int* inside,
                   float* grid) {
+  const TempoCam* cam = (const TempoCam*)cam_;
   for (long i = 0; i < n; i++) {
-    TempoPix p = tempo_world_to_pixel(cam, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    TempoPix p = tempo_world_to_pixel(cam, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], unf);
     pix[2 * i] = p.px;
     pix[2 * i + 1] = p.py;
     inside[i] = p.inside;
-    tempo_pixel_to_grid(cam, p.px, p.py, hm_w, hm_h, img_w, img_h, &grid[2 * i],
+    tempo_pixel_to_grid(cam, p.px, p.py, hm_w, hm_h, img_w, img_h, unf, &grid[2 * i],
                         &grid[2 * i + 1]);
   }
 }
@@ -33,17 +34,17 @@ static float texel(const float* hm, int W, int H, int CP, int x, int y, int c) {
 // bounds test.  Returns the valid-view bitmask.
 static unsigned voxel(const float* hm, const float* cam, int V, int C, int CP,
                       int H, int W, float x, float y, float z, int root,
-                      float hm_w, float hm_h, float img_w, float img_h, float* out) {
+                      float hm_w, float hm_h, float img_w, float img_h, int unf, float* out) {
   float acc[64];
   for (int c = 0; c < C; c++) acc[c] = 0.0f;
   int cnt = 0;
   unsigned bits = 0;
   for (int s = 0; s < V; s++) {
     const int v = tempo_view_of_slot(s, V);
-    const float* cm = cam + v * CAM_FLOATS;
-    TempoPix p = tempo_world_to_pixel(cm, x, y, z);
+    const TempoCam* cm = (const TempoCam*)(cam + v * CAM_FLOATS);
+    TempoPix p = tempo_world_to_pixel(cm, x, y, z, unf);
     float gx, gy;
-    tempo_pixel_to_grid(cm, p.px, p.py, hm_w, hm_h, img_w, img_h, &gx, &gy);
+    tempo_pixel_to_grid(cm, p.px, p.py, hm_w, hm_h, img_w, img_h, unf, &gx, &gy);
     TempoTap t = tempo_bilinear_tap(gx, gy, W, H);
     const int skip = root && !p.inside && gx == gx && gy == gy;
     cnt += p.inside;
@@ -69,7 +70,7 @@ static unsigned voxel(const float* hm, const float* cam, int V, int C, int CP,
 void emul_root(const float* hm, const float* cam, const float* ax, const float* ay,
                const float* az, const uint8_t* live, int B, int V, int C, int CP, int H,
                int W, int X, int Y, int Z, float hm_w, float hm_h, float img_w,
-               float img_h, float* cubes, uint32_t* mask) {
+               float img_h, int unf, float* cubes, uint32_t* mask) {
   const long N = (long)X * Y * Z;
   float out[64];
   for (int b = 0; b < B; b++)
@@ -80,7 +81,7 @@ void emul_root(const float* hm, const float* cam, const float* ax, const float* 
         for (int c = 0; c < C; c++) out[c] = 0.0f;
       } else {
         bits = voxel(hm + (long)b * V * H * W * CP, cam + (long)b * V * CAM_FLOATS, V, C,
-                     CP, H, W, ax[ix], ay[iy], az[iz], 1, hm_w, hm_h, img_w, img_h, out);
+                     CP, H, W, ax[ix], ay[iy], az[iz], 1, hm_w, hm_h, img_w, img_h, unf, out);
       }
       for (int c = 0; c < C; c++) cubes[((long)b * C + c) * N + n] = out[c];
       mask[(long)b * N + n] = bits;
@@ -91,7 +92,7 @@ void emul_root(const float* hm, const float* cam, const float* ax, const float* 
 void emul_window(const float* hm, const float* cam, const float* fx, const float* fy,
                  const float* fz, const int* tl, const int* st, const int* en,
                  const uint8_t* live, int NW, int V, int C, int CP, int H, int W, int VX,
-                 int VY, int VZ, float hm_w, float hm_h, float img_w, float img_h,
+                 int VY, int VZ, float hm_w, float hm_h, float img_w, float img_h, int unf,
                  float* cubes) {
   const long N = (long)VX * VY * VZ;
   float out[64];
@@ -104,7 +105,7 @@ void emul_window(const float* hm, const float* cam, const float* fx, const float
                       f2 >= st[3 * b + 2] && f2 < en[3 * b + 2];
       if (act)
         voxel(hm + (long)b * V * H * W * CP, cam + (long)b * V * CAM_FLOATS, V, C, CP, H, W,
-              fx[f0], fy[f1], fz[f2], 0, hm_w, hm_h, img_w, img_h, out);
+              fx[f0], fy[f1], fz[f2], 0, hm_w, hm_h, img_w, img_h, unf, out);
       else
         for (int c = 0; c < C; c++) out[c] = 0.0f;
       for (int c = 0; c < C; c++) cubes[((long)b * C + c) * N + n] = out[c];

@@ -6,7 +6,7 @@ import ctypes
 import numpy as np
 import torch
 
-from tempo_amd import project_layer as PL
+from tempo_amd import numerics, project_layer as PL
 from tempo_amd.camera import pack_cameras
 
 
@@ -51,7 +51,8 @@ def run_root(emul, case, mm_mode='auto'):
                        _p(lv) if lv is not None else None, 1, V, C, cp, H, W, X, Y, Z,
                        f(layer.heatmap_size[0]), f(layer.heatmap_size[1]),
                        f(layer.image_size[0]), f(layer.image_size[1]),
-                       _p(cubes[b:b + 1]), _p(mask[b:b + 1]))
+                       int(numerics.abi_flag(mm_mode) != 0), _p(cubes[b:b + 1]),
+                       _p(mask[b:b + 1]))
     return cubes.reshape(B, C, X, Y, Z), mask
 
 
@@ -76,5 +77,6 @@ def run_window(emul, case, mm_mode='auto'):
     emul.emul_window(_p(hm), _p(cam), _p(fa[0]), _p(fa[1]), _p(fa[2]), _p(tl), _p(st),
                      _p(en), _p(live), B, V, C, cp, H, W, VX, VY, VZ,
                      f(layer.heatmap_size[0]), f(layer.heatmap_size[1]),
-                     f(layer.image_size[0]), f(layer.image_size[1]), _p(cubes))
+                     f(layer.image_size[0]), f(layer.image_size[1]),
+                     int(numerics.abi_flag(mm_mode) != 0), _p(cubes))
     return cubes.reshape(B, C, VX, VY, VZ), offset, layer.center_grid

@@ -64,7 +64,7 @@ for v, cam in enumerate(cams):
     epix = np.zeros((n, 2), np.float32); eins = np.zeros(n, np.int32); eg = np.zeros((n, 2), np.float32)
     rec = table[v].numpy().copy(); gn = grid.numpy().copy()
     f = ctypes.c_float
-    emul.emul_project(P(rec), P(gn), ctypes.c_long(n), f(w), f(h), f(cfg['image_size'][0]), f(cfg['image_size'][1]), P(epix), P(eins), P(eg))
+    emul.emul_project(P(rec), P(gn), ctypes.c_long(n), f(w), f(h), f(cfg['image_size'][0]), f(cfg['image_size'][1]), int(numerics.abi_flag('auto') != 0), P(epix), P(eins), P(eg))
     msg = f'view {v}: emul(cpu) vs oracle(here) pix ndiff {int((epix.view(np.int32) != xy.numpy().view(np.int32)).sum())}'
     if torch.cuda.is_available():
         msg += f' | gpu vs emul pix ndiff {int((pix[v].cpu().numpy().view(np.int32) != epix.view(np.int32)).sum())} grid ndiff {int((g[v].cpu().numpy().view(np.int32) != eg.view(np.int32)).sum())}'
