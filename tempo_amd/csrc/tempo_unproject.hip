@@ -37,6 +37,7 @@ constexpr int MODE_ROOT = 0;
 constexpr int MODE_WINDOW = 1;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define TEMPO_AS4 __attribute__((address_space(4)))
 
 struct UnprojArgs {
@@ -67,7 +68,25 @@ struct UnprojArgs {
   int mask_bytes;
   int n_slots;  // view slots, padded to a multiple of VU
   float hm_w, hm_h, img_w, img_h;
+  unsigned order[10];  // slot -> view in torch's summation order (one byte per slot, 255 = empty)
 };
+
+#ifndef TEMPO_OPT_SKIPA
+#define TEMPO_OPT_SKIPA 1
+#endif
+#ifndef TEMPO_OPT_SKIPB
+#define TEMPO_OPT_SKIPB 0
+#endif
+#ifndef TEMPO_OPT_BATCH
+#define TEMPO_OPT_BATCH 1
+#endif
+#ifndef TEMPO_OPT_PK
+#define TEMPO_OPT_PK 1
+#endif
+
+__device__ __forceinline__ int slot_view(const UnprojArgs& a, int slot) {
+  return (int)((a.order[slot >> 2] >> ((slot & 3) * 8)) & 255u);
+}
 
 // wave-uniform read through the scalar data cache (constant address space)
 template <typename T>
@@ -173,35 +192,49 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
     }
 #pragma unroll 1
     for (int slot = 0; slot < a.n_slots; slot++) {
-      const int view = tempo_view_of_slot(slot, a.V);
+      const int view = slot_view(a, slot);  // 255 = empty slot
       u32x4 off = {kInvalid, kInvalid, kInvalid, kInvalid};
       float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (view >= 0) {  // wave-uniform
+      if (view < a.V) {  // wave-uniform
         const TempoCam cam = load_cam(a.cam, (long long)frame * a.V + view);
+        TempoPix p;
+        p.px = p.py = 0.f;
+        p.inside = 0;
+        bool need = false;
         if (have) {
-          const TempoPix p = tempo_world_to_pixel(&cam, x, y, z, UNF);
+          p = tempo_world_to_pixel(&cam, x, y, z, UNF);
+          // root: a view that fails the bounds test is multiplied by 0 in the
+          // reference, so its texels are never fetched -- unless a coordinate
+          // is NaN: then the reference's 0 * NaN poisons the voxel and so must we
+          need = MODE != MODE_ROOT || p.inside || p.px != p.px || p.py != p.py;
+        }
+        if (!TEMPO_OPT_SKIPA || __builtin_amdgcn_ballot_w64(need) != 0) {  // whole wave out of this view: skip
           float gx, gy;
           tempo_pixel_to_grid(&cam, p.px, p.py, a.hm_w, a.hm_h, a.img_w, a.img_h, UNF, &gx,
                               &gy);
           const TempoTap t = tempo_bilinear_tap(gx, gy, a.W, a.H);
-          // root: a view that fails the bounds test is multiplied by 0 in the
-          // reference; skip its texels unless the coordinates are NaN (then the
-          // reference's 0 * NaN poisons the voxel and so must we).
-          const bool skip = (MODE == MODE_ROOT) && !p.inside && gx == gx && gy == gy;
+          // rows outside the map need no test: their byte offset is negative
+          // (wraps to > 2^31) or >= view_bytes, and the buffer load returns 0
           const bool x0ok = (unsigned)t.x0 < (unsigned)a.W;
           const bool x1ok = (unsigned)(t.x0 + 1) < (unsigned)a.W;
-          const bool y0ok = (unsigned)t.y0 < (unsigned)a.H && !skip;
-          const bool y1ok = (unsigned)(t.y0 + 1) < (unsigned)a.H && !skip;
+          const bool anyrow = (unsigned)(t.y0 + 1) < (unsigned)(a.H + 1);
           const unsigned base = (unsigned)((t.y0 * a.W + t.x0) * CPB);
           const unsigned row = (unsigned)(a.W * CPB);
-          off.x = (x0ok && y0ok) ? base : kInvalid;
-          off.y = (x1ok && y0ok) ? base + CPB : kInvalid;
-          off.z = (x0ok && y1ok) ? base + row : kInvalid;
-          off.w = (x1ok && y1ok) ? base + row + CPB : kInvalid;
-          if (MODE == MODE_ROOT) off.x |= (unsigned)p.inside;  // bit 0 rides along
-          wt = make_float4(t.nw, t.ne, t.sw, t.se);
+          if (need) {
+            off.x = x0ok ? base : kInvalid;
+            off.y = x1ok ? base + CPB : kInvalid;
+            off.z = x0ok ? base + row : kInvalid;
+            off.w = x1ok ? base + row + CPB : kInvalid;
+            // bit 1: at least one texel of the footprint lies inside the map
+            off.x = (off.x & ~15u) | (((x0ok | x1ok) & anyrow) ? 2u : 0u);
+            wt = make_float4(t.nw, t.ne, t.sw, t.se);
+          }
         }
+        if (MODE == MODE_ROOT) off.x |= (unsigned)p.inside;  // bit 0: passes the bounds test
       }
+#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 1  // no gather traffic
+      off.x = kInvalid | (off.x & 1u); off.y = off.z = off.w = kInvalid;
+#endif
       s_off[slot * kWaveVox + lane] = off;
       s_wt[slot * kWaveVox + lane] = wt;
     }
@@ -221,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
     const int vsl = s * VPS + vq;
     const bool on = lane_on && vsl < kWaveVox && n0 + vsl < a.N;
     const int rd = on ? vsl : 0;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
     int cnt = 0;
     unsigned mbits = 0;
 #pragma unroll 1
@@ -229,6 +262,7 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
       u32x4 o[VU];
       float4 w[VU];
       u32x4 tex[VU][4];
+      bool fetch[VU];
 #pragma unroll
       for (int u = 0; u < VU; u++) {
         o[u] = s_off[(g0 + u) * kWaveVox + rd];
@@ -236,28 +270,57 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
       }
 #pragma unroll
       for (int u = 0; u < VU; u++) {
-        const int view = tempo_view_of_slot(g0 + u, a.V);
-        const char* vbase = fbase + (long long)(view < 0 ? 0 : view) * a.view_bytes;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<char*>(vbase), 0, (int)a.view_bytes, 0x00020000);
-        tex[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (o[u].x & ~15u) + lo, 0, 0);
-        tex[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].y + lo, 0, 0);
-        tex[u][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].z + lo, 0, 0);
-        tex[u][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].w + lo, 0, 0);
+        // no voxel of this sub-step sees this view: no fetch, no arithmetic
+        fetch[u] = !TEMPO_OPT_SKIPB || __builtin_amdgcn_ballot_w64(on && (o[u].x & 2u)) != 0;
+        if (fetch[u]) {
+          const int view = slot_view(a, g0 + u) & 31;
+          const char* vbase = fbase + (long long)view * a.view_bytes;
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+              const_cast<char*>(vbase), 0, (int)a.view_bytes, 0x00020000);
+          tex[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (o[u].x & ~15u) + lo, 0, 0);
+          tex[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].y + lo, 0, 0);
+          tex[u][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].z + lo, 0, 0);
+          tex[u][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].w + lo, 0, 0);
+        }
       }
+#if TEMPO_OPT_BATCH
+      // all VU*4 fetches of the sub-step are in flight before the first mix
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int u = 0; u < VU; u++) {
-        const int view = tempo_view_of_slot(g0 + u, a.V);
         const unsigned in = o[u].x & 1u;
         cnt += (int)in;
-        if (view >= 0) mbits |= in << view;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const float v = tempo_bilinear_mix(
-              __uint_as_float(tex[u][0][c]), __uint_as_float(tex[u][1][c]),
-              __uint_as_float(tex[u][2][c]), __uint_as_float(tex[u][3][c]), w[u].x,
-              w[u].y, w[u].z, w[u].w);
-          acc[c] = acc[c] + v;
+        mbits |= in << (slot_view(a, g0 + u) & 31);
+        if (fetch[u]) {
+          // channels 4cq..4cq+3 as two packed pairs; same chain as
+          // tempo_bilinear_mix, then the view sum
+          const f32x2 a01 = {__uint_as_float(tex[u][0][0]), __uint_as_float(tex[u][0][1])};
+          const f32x2 a23 = {__uint_as_float(tex[u][0][2]), __uint_as_float(tex[u][0][3])};
+          const f32x2 b01 = {__uint_as_float(tex[u][1][0]), __uint_as_float(tex[u][1][1])};
+          const f32x2 b23 = {__uint_as_float(tex[u][1][2]), __uint_as_float(tex[u][1][3])};
+          const f32x2 c01 = {__uint_as_float(tex[u][2][0]), __uint_as_float(tex[u][2][1])};
+          const f32x2 c23 = {__uint_as_float(tex[u][2][2]), __uint_as_float(tex[u][2][3])};
+          const f32x2 d01 = {__uint_as_float(tex[u][3][0]), __uint_as_float(tex[u][3][1])};
+          const f32x2 d23 = {__uint_as_float(tex[u][3][2]), __uint_as_float(tex[u][3][3])};
+          const f32x2 nw = {w[u].x, w[u].x}, ne = {w[u].y, w[u].y};
+          const f32x2 sw = {w[u].z, w[u].z}, se = {w[u].w, w[u].w};
+#if TEMPO_OPT_PK
+          f32x2 v01 = a01 * nw, v23 = a23 * nw;
+          v01 = __builtin_elementwise_fma(b01, ne, v01);
+          v23 = __builtin_elementwise_fma(b23, ne, v23);
+          v01 = __builtin_elementwise_fma(c01, sw, v01);
+          v23 = __builtin_elementwise_fma(c23, sw, v23);
+          v01 = __builtin_elementwise_fma(d01, se, v01);
+          v23 = __builtin_elementwise_fma(d23, se, v23);
+          acc01 = acc01 + v01;
+          acc23 = acc23 + v23;
+#else
+          acc01.x = acc01.x + tempo_bilinear_mix(a01.x, b01.x, c01.x, d01.x, nw.x, ne.x, sw.x, se.x);
+          acc01.y = acc01.y + tempo_bilinear_mix(a01.y, b01.y, c01.y, d01.y, nw.x, ne.x, sw.x, se.x);
+          acc23.x = acc23.x + tempo_bilinear_mix(a23.x, b23.x, c23.x, d23.x, nw.x, ne.x, sw.x, se.x);
+          acc23.y = acc23.y + tempo_bilinear_mix(a23.y, b23.y, c23.y, d23.y, nw.x, ne.x, sw.x, se.x);
+#endif
         }
       }
     }
@@ -266,10 +329,15 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
     // (64/L)*4 bytes per channel plane, merged to full lines in L2
     if (on) {
       const float den = (MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f;
+      const float acc[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
       float* dst = a.cubes + ((long long)b * a.C + 4 * cq) * a.N + n0 + vsl;
 #pragma unroll
       for (int c = 0; c < 4; c++)
+#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 2  // (almost) no stores
+        if (4 * cq + c < a.C && acc[c] == 123.456f)
+#else
         if (4 * cq + c < a.C)
+#endif
           dst[(long long)c * a.N] = tempo_nan_clamp(acc[c] / den, 0.0f, 1.0f);
       if (MODE == MODE_ROOT && a.mask != nullptr && cq == 0) {
         char* m = (char*)a.mask + ((long long)b * a.N + n0 + vsl) * a.mask_bytes;
@@ -339,6 +407,11 @@ template <int MODE, int L, int VU, int UNF>
 int launch_one(const UnprojArgs& a, hipStream_t stream) {
   UnprojArgs k = a;
   k.n_slots = ((a.V + VU - 1) / VU) * VU;
+  for (int w = 0; w < 10; w++) k.order[w] = 0xffffffffu;
+  for (int sl = 0; sl < k.n_slots; sl++) {
+    const int v = tempo_view_of_slot(sl, a.V);
+    if (v >= 0) k.order[sl >> 2] = (k.order[sl >> 2] & ~(255u << ((sl & 3) * 8))) | ((unsigned)v << ((sl & 3) * 8));
+  }
   // wave-private LDS holds every view's records; fewer waves per workgroup when
   // many views would not fit 64 KB
   const size_t per_wave = (size_t)k.n_slots * kWaveVox * 32;

@@ -65,6 +65,11 @@ TEMPO_HD float tempo_nan_clamp(float v, float lo, float hi) {
   return v != v ? v : r;
 }
 
+// clamp for values known not to be NaN (fminf/fmaxf drop a NaN operand)
+TEMPO_HD float tempo_clamp(float v, float lo, float hi) {
+  return fminf(fmaxf(v, lo), hi);
+}
+
 // world point -> source-image pixel (SimpleCameraTorch.world_to_pixel)
 TEMPO_HD TempoPix tempo_world_to_pixel(const TempoCam* cam, float x, float y,
                                        float z, int unfused) {
@@ -107,8 +112,11 @@ TEMPO_HD void tempo_pixel_to_grid(const TempoCam* cam, float px, float py,
                                   float hm_w, float hm_h, float img_w, float img_h,
                                   int unfused, float* gx, float* gy) {
   const float wmax = cam->width > cam->height ? cam->width : cam->height;
-  px = tempo_nan_clamp(px, -1.0f, wmax);
-  py = tempo_nan_clamp(py, -1.0f, wmax);
+  // torch.clamp keeps NaN; the affine below mixes px and py (0 * NaN = NaN), so
+  // one NaN coordinate makes both outputs NaN: clamp NaN-blind, patch at the end
+  const int poisoned = (px != px) | (py != py);
+  px = tempo_clamp(px, -1.0f, wmax);
+  py = tempo_clamp(py, -1.0f, wmax);
   const float* t = cam->trans;
   // torch.mm(t, [x y 1]^T)
   float ax = tempo_dot3(t[0], px, t[1], py, t[2], 1.0f, unfused);
@@ -117,8 +125,9 @@ TEMPO_HD void tempo_pixel_to_grid(const TempoCam* cam, float px, float py,
   ay = (ay * hm_h) / img_h;
   float sx = (ax / (hm_w - 1.0f)) * 2.0f - 1.0f;
   float sy = (ay / (hm_h - 1.0f)) * 2.0f - 1.0f;
-  *gx = tempo_nan_clamp(sx, -1.1f, 1.1f);
-  *gy = tempo_nan_clamp(sy, -1.1f, 1.1f);
+  const float nan = __builtin_nanf("");
+  *gx = poisoned ? nan : tempo_clamp(sx, -1.1f, 1.1f);
+  *gy = poisoned ? nan : tempo_clamp(sy, -1.1f, 1.1f);
 }
 
 // grid_sample(align_corners=False) unnormalisation ((g + 1) * size - 1) / 2.

@@ -124,8 +124,11 @@ def test_projection_chain_bit_exact(gpu_device):
             sg = torch.clamp(O._sample_coords(xy, trans, w, h, cfg['image_size'], width,
                                               height, 'cpu'), -1.1, 1.1)
             assert torch.equal(inside[v].cpu().bool(), ins)
-            assert torch.equal(pix[v].cpu().view(torch.int32), xy.view(torch.int32))
-            assert torch.equal(g[v].cpu().view(torch.int32), sg.view(torch.int32))
+            # bit patterns, with every NaN mapped to one pattern (a voxel on a
+            # camera's principal plane projects to NaN in the reference too)
+            canon = lambda t: torch.nan_to_num(t, nan=-7777.0).view(torch.int32)
+            assert torch.equal(canon(pix[v].cpu()), canon(xy))
+            assert torch.equal(canon(g[v].cpu()), canon(sg))
 
 
 def test_repack_matches_permute(gpu_device):
