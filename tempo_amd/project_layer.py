@@ -109,11 +109,19 @@ class ProjectLayer(nn.Module):
         return None if all(flags) else torch.tensor(flags, dtype=torch.uint8, device=device)
 
     def get_voxel(self, feature_maps, grid_size, grid_center, cube_size, centers,
-                  scales, cameras):
+                  scales, cameras, zslab=None):
+        """``zslab=(z0, z1)`` (extension, used by ``tempo_amd.parallel``): compute
+        only planes ``[z0, z1)`` of the grid; returns ``[B,C,X,Y,z1-z0]``."""
         device = _check_inputs(feature_maps)
         B, C = feature_maps[0].shape[:2]
         live = self._live(grid_center, B, device)
         axes, cube_size = self._axes(grid_size, grid_center, cube_size, B, device)
+        if zslab is not None:
+            z0, z1 = zslab
+            if not 0 <= z0 < z1 <= cube_size[2]:
+                raise ValueError(f'zslab {zslab} outside [0, {cube_size[2]}]')
+            axes[2] = axes[2][..., z0:z1].contiguous()
+            cube_size = [cube_size[0], cube_size[1], z1 - z0]
         cam = pack_cameras(centers, scales, cameras, self.image_size,
                            self.mm_mode).to(device)
         cubes = torch.empty(B, C, *cube_size, dtype=torch.float32, device=device)

@@ -1,0 +1,70 @@
+"""The C-ABI library loads without a GPU, exports every symbol the header
+declares, and rejects bad arguments before touching the device."""
+import ctypes
+import os
+import re
+
+from tempo_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'tempo_unproject.h')
+
+
+def _declared():
+    text = re.sub(r'/\*.*?\*/', '', open(HEADER).read(), flags=re.S)
+    return sorted(set(re.findall(r'\b(tempo_[a-z_]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    names = _declared()
+    assert names == sorted(_lib.SIGNATURES), (names, sorted(_lib.SIGNATURES))
+    text = re.sub(r'/\*.*?\*/', '', open(HEADER).read(), flags=re.S)
+    for name, (_, args) in _lib.SIGNATURES.items():
+        decl = re.search(name + r'\s*\((.*?)\)\s*;', text, flags=re.S).group(1).strip()
+        n = 0 if decl == 'void' else len(decl.split(','))
+        assert n == len(args), (name, n, len(args))
+
+
+def test_library_exports_every_symbol():
+    lib = _lib.load()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert getattr(raw, name) is not None
+    assert lib.tempo_version() == _lib.ABI_VERSION
+    assert lib.tempo_error_string(0) == b'ok'
+    assert b'NULL' in lib.tempo_error_string(-1)
+
+
+def test_padded_channels():
+    lib = _lib.load()
+    assert [lib.tempo_padded_channels(c) for c in (1, 15, 16, 17, 20, 21, 32)] == \
+        [16, 16, 16, 20, 20, 24, 32]
+    assert lib.tempo_padded_channels(0) < 0 and lib.tempo_padded_channels(33) < 0
+
+
+def test_bad_arguments_are_rejected_before_any_launch():
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    one = P(16)  # never dereferenced: every call below must fail validation first
+    root = lambda **kw: lib.tempo_unproject_root(
+        kw.get('hm', one), one, one, one, one, 0, None, kw.get('cubes', one), None,
+        kw.get('mask', None), kw.get('mask_bytes', 0), kw.get('B', 1), kw.get('V', 5),
+        kw.get('C', 15), kw.get('CP', 16), 128, 240, 80, 80, kw.get('Z', 20), 240.0, 128.0,
+        960.0, 512.0, kw.get('mm', 0), None)
+    assert root(hm=None) == -1 and root(cubes=None) == -1
+    assert root(V=0) == -2 and root(V=33) == -2 and root(C=33) == -2 and root(Z=0) == -2
+    assert root(CP=12) == -3 and root(CP=18) == -3 and root(C=17, CP=16) == -3
+    assert root(mask=one, mask_bytes=0) == -5 and root(mask_bytes=1) == -5
+    assert root(mask=one, mask_bytes=1, V=9, CP=16) == -5
+    assert root(mm=3) == -5
+    win = lambda **kw: lib.tempo_unproject_window(
+        one, one, kw.get('wf', None), one, one, one, kw.get('tl', one), one, one, None, one,
+        kw.get('NW', 4), kw.get('F', 4), 5, 15, 16, 128, 240, 253, 253, 64, 64, 64, 64,
+        240.0, 128.0, 960.0, 512.0, 0, None)
+    assert win(tl=None) == -1
+    assert win(NW=8, F=4) == -5  # more windows than frames needs win_frame
+    assert win(NW=0) == -2
+    ptrs = (ctypes.c_void_p * 2)(16, 16)
+    assert lib.tempo_repack_nhwc(ptrs, 2, 1, 15, 0, 15, 8, 8, 16, None, None) == -1
+    assert lib.tempo_repack_nhwc(ptrs, 2, 1, 15, 4, 15, 8, 8, 16, one, None) == -2
+    assert lib.tempo_project_points(one, one, 0, 5, 1., 1., 1., 1., 0, one, one, one, None) == -2
