@@ -37,7 +37,7 @@ constexpr int MODE_ROOT = 0;
 constexpr int MODE_WINDOW = 1;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef tempo_f2 f32x2;
 #define TEMPO_AS4 __attribute__((address_space(4)))
 
 struct UnprojArgs {
@@ -67,7 +67,7 @@ struct UnprojArgs {
   int chunk;    // ceil(total / 8): contiguous run of work items per XCD label
   int mask_bytes;
   int n_slots;  // view slots, padded to a multiple of VU
-  float hm_w, hm_h, img_w, img_h;
+  TempoGeom geom;
   unsigned order[10];  // slot -> view in torch's summation order (one byte per slot, 255 = empty)
 };
 
@@ -210,8 +210,7 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
         }
         if (!TEMPO_OPT_SKIPA || __builtin_amdgcn_ballot_w64(need) != 0) {  // whole wave out of this view: skip
           float gx, gy;
-          tempo_pixel_to_grid(&cam, p.px, p.py, a.hm_w, a.hm_h, a.img_w, a.img_h, UNF, &gx,
-                              &gy);
+          tempo_pixel_to_grid(&cam, p.px, p.py, &a.geom, UNF, &gx, &gy);
           const TempoTap t = tempo_bilinear_tap(gx, gy, a.W, a.H);
           // rows outside the map need no test: their byte offset is negative
           // (wraps to > 2^31) or >= view_bytes, and the buffer load returns 0
@@ -264,10 +263,7 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
       u32x4 tex[VU][4];
       bool fetch[VU];
 #pragma unroll
-      for (int u = 0; u < VU; u++) {
-        o[u] = s_off[(g0 + u) * kWaveVox + rd];
-        w[u] = s_wt[(g0 + u) * kWaveVox + rd];
-      }
+      for (int u = 0; u < VU; u++) o[u] = s_off[(g0 + u) * kWaveVox + rd];
 #pragma unroll
       for (int u = 0; u < VU; u++) {
         // no voxel of this sub-step sees this view: no fetch, no arithmetic
@@ -284,9 +280,12 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
         }
       }
 #if TEMPO_OPT_BATCH
-      // all VU*4 fetches of the sub-step are in flight before the first mix
+      // all VU*4 fetches of the sub-step are in flight before the first mix;
+      // the weights are read only now, so they do not sit in registers meanwhile
       __builtin_amdgcn_sched_barrier(0);
 #endif
+#pragma unroll
+      for (int u = 0; u < VU; u++) w[u] = s_wt[(g0 + u) * kWaveVox + rd];
 #pragma unroll
       for (int u = 0; u < VU; u++) {
         const unsigned in = o[u].x & 1u;
@@ -328,8 +327,13 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
     // 64/L consecutive voxels x 4 channels per store instruction: runs of
     // (64/L)*4 bytes per channel plane, merged to full lines in L2
     if (on) {
+      // masked mean: sum / (count + 1e-6).  One IEEE reciprocal of the shared
+      // denominator, then the exact constant-divisor division on channel pairs
       const float den = (MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f;
-      const float acc[4] = {acc01.x, acc01.y, acc23.x, acc23.y};
+      const float rden = 1.0f / den;
+      const f32x2 q01 = tempo_div_const2(acc01, tempo_splat(den), tempo_splat(rden));
+      const f32x2 q23 = tempo_div_const2(acc23, tempo_splat(den), tempo_splat(rden));
+      const float acc[4] = {q01.x, q01.y, q23.x, q23.y};
       float* dst = a.cubes + ((long long)b * a.C + 4 * cq) * a.N + n0 + vsl;
 #pragma unroll
       for (int c = 0; c < 4; c++)
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
 #else
         if (4 * cq + c < a.C)
 #endif
-          dst[(long long)c * a.N] = tempo_nan_clamp(acc[c] / den, 0.0f, 1.0f);
+          dst[(long long)c * a.N] = tempo_nan_clamp(acc[c], 0.0f, 1.0f);
       if (MODE == MODE_ROOT && a.mask != nullptr && cq == 0) {
         char* m = (char*)a.mask + ((long long)b * a.N + n0 + vsl) * a.mask_bytes;
         if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mbits;
@@ -383,8 +387,8 @@ __global__ __launch_bounds__(kThreads) void repack_kernel(const RepackArgs a) {
 
 // ---------------------------------------------------------- project points
 __global__ __launch_bounds__(kThreads) void project_points_kernel(
-    const float* __restrict__ pts, const float* __restrict__ cam, int N, float hm_w,
-    float hm_h, float img_w, float img_h, int unfused, float* __restrict__ pix,
+    const float* __restrict__ pts, const float* __restrict__ cam, int N,
+    const TempoGeom geom, int unfused, float* __restrict__ pix,
     float* __restrict__ grid, uint8_t* __restrict__ inside) {
   const int m = blockIdx.y;
   const int n = blockIdx.x * kThreads + threadIdx.x;
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(kThreads) void project_points_kernel(
   const TempoPix p =
       tempo_world_to_pixel(&c, pts[3 * n], pts[3 * n + 1], pts[3 * n + 2], unfused);
   float gx, gy;
-  tempo_pixel_to_grid(&c, p.px, p.py, hm_w, hm_h, img_w, img_h, unfused, &gx, &gy);
+  tempo_pixel_to_grid(&c, p.px, p.py, &geom, unfused, &gx, &gy);
   const long long o = (long long)m * N + n;
   pix[2 * o] = p.px;
   pix[2 * o + 1] = p.py;
@@ -539,7 +543,7 @@ int tempo_unproject_root(const float* hm, const float* cam, const float* ax_x,
   a.view_bytes = (unsigned)((long long)H * W * CP * 4);
   a.NB = B; a.F = B; a.V = V; a.C = C; a.CP = CP; a.H = H; a.W = W;
   a.dim[0] = X; a.dim[1] = Y; a.dim[2] = Z; a.N = (int)N;
-  a.hm_w = hm_w; a.hm_h = hm_h; a.img_w = img_w; a.img_h = img_h;
+  a.geom = tempo_make_geom(hm_w, hm_h, img_w, img_h);
   return launch_mode<MODE_ROOT>(a, mm_unfused, (hipStream_t)stream);
 }
 
@@ -569,7 +573,7 @@ int tempo_unproject_window(const float* hm, const float* cam, const int32_t* win
   a.NB = NW; a.F = F; a.V = V; a.C = C; a.CP = CP; a.H = H; a.W = W;
   a.dim[0] = VX; a.dim[1] = VY; a.dim[2] = VZ; a.N = (int)N;
   a.fdim[0] = FX; a.fdim[1] = FY; a.fdim[2] = FZ;
-  a.hm_w = hm_w; a.hm_h = hm_h; a.img_w = img_w; a.img_h = img_h;
+  a.geom = tempo_make_geom(hm_w, hm_h, img_w, img_h);
   return launch_mode<MODE_WINDOW>(a, mm_unfused, (hipStream_t)stream);
 }
 
@@ -581,7 +585,7 @@ int tempo_project_points(const float* pts, const float* cam, int M, int N, float
   if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
   dim3 g((N + kThreads - 1) / kThreads, M);
   hipLaunchKernelGGL(project_points_kernel, g, dim3(kThreads), 0, (hipStream_t)stream, pts,
-                     cam, N, hm_w, hm_h, img_w, img_h, mm_unfused != 0, pix, grid, inside);
+                     cam, N, tempo_make_geom(hm_w, hm_h, img_w, img_h), mm_unfused != 0, pix, grid, inside);
   return (int)hipGetLastError();
 }
 

@@ -46,11 +46,126 @@ enum { CAM_FLOATS = 32 };
 // flavour bits of the three matmul sites (argument `mm_unfused` of the ABI)
 enum { TEMPO_UNFUSED_R = 1, TEMPO_UNFUSED_K = 2, TEMPO_UNFUSED_A = 4, TEMPO_UNFUSED_ALL = 7 };
 
+// ---- pairs: the x and y coordinate go through identical operation chains, so
+// they are carried as 2-vectors; on gfx950 these become packed-fp32 VALU ops
+// (v_pk_mul/add/fma_f32: two lanes' worth per issue slot)
+#if defined(__HIPCC__)
+typedef float tempo_f2 __attribute__((ext_vector_type(2)));
+#define TEMPO_FMA2(a, b, c) __builtin_elementwise_fma((a), (b), (c))
+#else
+typedef float tempo_f2 __attribute__((vector_size(8)));
+static inline tempo_f2 TEMPO_FMA2(tempo_f2 a, tempo_f2 b, tempo_f2 c) {
+  tempo_f2 r = {fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])};
+  return r;
+}
+#endif
+TEMPO_HD tempo_f2 tempo_splat(float v) {
+  tempo_f2 r = {v, v};
+  return r;
+}
+TEMPO_HD tempo_f2 tempo_pair(float a, float b) {
+  tempo_f2 r = {a, b};
+  return r;
+}
+
 // sum_k a_k * b_k, k ascending, in the flavour the host BLAS uses
 TEMPO_HD float tempo_dot3(float a0, float b0, float a1, float b1, float a2,
                           float b2, int unfused) {
   if (unfused) return (a0 * b0 + a1 * b1) + a2 * b2;
   return fmaf(a2, b2, fmaf(a1, b1, a0 * b0));
+}
+TEMPO_HD tempo_f2 tempo_dot3_2(tempo_f2 a0, tempo_f2 b0, tempo_f2 a1, tempo_f2 b1,
+                               tempo_f2 a2, tempo_f2 b2, int unfused) {
+  if (unfused) return (a0 * b0 + a1 * b1) + a2 * b2;
+  return TEMPO_FMA2(a2, b2, TEMPO_FMA2(a1, b1, a0 * b0));
+}
+
+// ---- exact IEEE division without the hardware's scaling preamble.
+// a / b for a divisor known on the host, rb = RN(1/b) (tempo_rcp_rn): one
+// multiply and two FMA correction steps.  The first step leaves q within one
+// ulp; with a correctly rounded reciprocal the second is then correctly rounded
+// (Markstein's theorem), provided no intermediate leaves the normal range --
+// hence the magnitude guard, outside of which the plain division runs.  Checked
+// against a / b over every float in the guarded range for the divisors of the
+// shipped configs (tools/verify_constdiv.c).  One deviation: -0 / b gives +0.
+TEMPO_HD tempo_f2 tempo_div_const2(tempo_f2 a, tempo_f2 b, tempo_f2 rb) {
+  tempo_f2 q = a * rb;
+  tempo_f2 r = TEMPO_FMA2(-b, q, a);
+  q = TEMPO_FMA2(r, rb, q);
+  r = TEMPO_FMA2(-b, q, a);
+  q = TEMPO_FMA2(r, rb, q);
+  // a zero numerator is exact on the fast path; tiny, huge or non-finite ones are not
+  const float m0 = fabsf(a[0]), m1 = fabsf(a[1]);
+  const int ok0 = (m0 == 0.0f) | ((m0 >= 0x1p-100f) & (m0 <= 0x1p100f));
+  const int ok1 = (m1 == 0.0f) | ((m1 >= 0x1p-100f) & (m1 <= 0x1p100f));
+  if (!(ok0 & ok1))
+    q = a / b;
+  return q;
+}
+
+// host side: the float nearest to 1/b (products of two floats are exact in
+// double, so |1 - c*b| ranks the candidates exactly)
+static inline float tempo_rcp_rn(float b) {
+  float y = (float)(1.0 / (double)b);
+  float best = y;
+  double err = fabs(1.0 - (double)y * (double)b);
+  const float cand[2] = {nextafterf(y, -INFINITY), nextafterf(y, INFINITY)};
+  for (int i = 0; i < 2; i++) {
+    const double e = fabs(1.0 - (double)cand[i] * (double)b);
+    if (e < err) {
+      err = e;
+      best = cand[i];
+    }
+  }
+  return best;
+}
+
+// [xc, yc] / zc: reciprocal estimate, one Newton step, then the same two
+// correction steps -- the operation sequence of the compiler's own fp32
+// division expansion minus its range scaling, shared between both numerators.
+// Outside the range where no scaling is needed (and for a zero numerator) the
+// plain division runs.  `rcp_est` may be any approximation within a few ulp.
+TEMPO_HD tempo_f2 tempo_div_shared2(tempo_f2 a, float b, float rcp_est) {
+  const float e = fmaf(-b, rcp_est, 1.0f);
+  const float r1 = fmaf(e, rcp_est, rcp_est);
+  const tempo_f2 rb = tempo_splat(r1), nb = tempo_splat(-b);
+  tempo_f2 q = a * rb;
+  tempo_f2 r = TEMPO_FMA2(nb, q, a);
+  q = TEMPO_FMA2(r, rb, q);
+  r = TEMPO_FMA2(nb, q, a);
+  q = TEMPO_FMA2(r, rb, q);
+  const float m0 = fabsf(a[0]), m1 = fabsf(a[1]), mb = fabsf(b);
+  const float hi = fmaxf(fmaxf(m0, m1), mb), lo = fminf(fminf(m0, m1), mb);
+  if (!(hi <= 0x1p60f) || !(lo >= 0x1p-60f)) q = a / tempo_splat(b);
+  return q;
+}
+TEMPO_HD float tempo_rcp_est(float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(b);
+#else
+  return 1.0f / b;
+#endif
+}
+
+// per-call constants of the pixel -> sample-grid chain
+typedef struct TempoGeom {
+  float hm[2];     // the module's heatmap_size (w, h)
+  float img[2];    // its image_size (w, h)
+  float hm1[2];    // heatmap_size - 1
+  float r_img[2];  // RN(1 / img)
+  float r_hm1[2];  // RN(1 / (heatmap_size - 1))
+} TempoGeom;
+
+static inline TempoGeom tempo_make_geom(float hm_w, float hm_h, float img_w, float img_h) {
+  TempoGeom g;
+  g.hm[0] = hm_w; g.hm[1] = hm_h;
+  g.img[0] = img_w; g.img[1] = img_h;
+  g.hm1[0] = hm_w - 1.0f; g.hm1[1] = hm_h - 1.0f;
+  for (int i = 0; i < 2; i++) {
+    g.r_img[i] = tempo_rcp_rn(g.img[i]);
+    g.r_hm1[i] = tempo_rcp_rn(g.hm1[i]);
+  }
+  return g;
 }
 
 typedef struct TempoPix {
@@ -75,42 +190,42 @@ TEMPO_HD TempoPix tempo_world_to_pixel(const TempoCam* cam, float x, float y,
                                        float z, int unfused) {
   const float* R = cam->R;
   // X @ R_w2c then + T_w2c (separate add)
-  float xc = tempo_dot3(x, R[0], y, R[3], z, R[6], unfused) + cam->T[0];
-  float yc = tempo_dot3(x, R[1], y, R[4], z, R[7], unfused) + cam->T[1];
-  float zc = tempo_dot3(x, R[2], y, R[5], z, R[8], unfused) + cam->T[2];
+  const tempo_f2 xy_c = tempo_dot3_2(tempo_splat(x), tempo_pair(R[0], R[1]), tempo_splat(y),
+                                     tempo_pair(R[3], R[4]), tempo_splat(z),
+                                     tempo_pair(R[6], R[7]), unfused) +
+                        tempo_pair(cam->T[0], cam->T[1]);
+  const float zc = tempo_dot3(x, R[2], y, R[5], z, R[8], unfused) + cam->T[2];
   // _X = X / X[..., 2:]   (no z > 0 test, as the reference)
-  float xn = xc / zc;
-  float yn = yc / zc;
+  tempo_f2 n = tempo_div_shared2(xy_c, zc, tempo_rcp_est(zc));
   // zc / zc: 1 for finite non-zero zc, NaN for 0 and +-inf
-  float zn = (zc != 0.0f && zc - zc == 0.0f) ? 1.0f : __builtin_nanf("");
+  const float zn = (zc != 0.0f && zc - zc == 0.0f) ? 1.0f : __builtin_nanf("");
   if (cam->has_dist != 0.0f) {
     const float k0 = cam->kd[0], k1 = cam->kd[1], k2 = cam->kd[2];
-    const float p0 = cam->pd[0], p1 = cam->pd[1];
-    float r2 = xn * xn + yn * yn;
-    float r4 = r2 * r2;  // r2**2
-    float r6 = r4 * r2;  // r2**3 = (r2*r2)*r2
-    float radial = 1.0f + ((k0 * r2 + k1 * r4) + k2 * r6);
-    float tang = 2.0f * (p1 * xn + p0 * yn);
-    float rt = radial + tang;
-    float xd = xn * rt + r2 * p1;
-    float yd = yn * rt + r2 * p0;
-    xn = xd;
-    yn = yd;
+    const tempo_f2 sq = n * n;
+    const float r2 = sq[0] + sq[1];
+    const float r4 = r2 * r2;  // r2**2
+    const float r6 = r4 * r2;  // r2**3 = (r2*r2)*r2
+    const float radial = 1.0f + ((k0 * r2 + k1 * r4) + k2 * r6);
+    const tempo_f2 tp = tempo_pair(cam->pd[1], cam->pd[0]) * n;  // p1*x, p0*y
+    const float tang = 2.0f * (tp[0] + tp[1]);
+    const float rt = radial + tang;
+    n = n * tempo_splat(rt) + tempo_splat(r2) * tempo_pair(cam->pd[1], cam->pd[0]);
   }
   const float* K = cam->K;
+  const tempo_f2 pix = tempo_dot3_2(tempo_splat(n[0]), tempo_pair(K[0], K[3]),
+                                    tempo_splat(n[1]), tempo_pair(K[1], K[4]),
+                                    tempo_splat(zn), tempo_pair(K[2], K[5]), unfused);
   TempoPix o;
-  o.px = tempo_dot3(xn, K[0], yn, K[1], zn, K[2], unfused);
-  o.py = tempo_dot3(xn, K[3], yn, K[4], zn, K[5], unfused);
+  o.px = pix[0];
+  o.py = pix[1];
   o.inside = (o.px >= 0.0f) & (o.py >= 0.0f) & (o.px < cam->width) & (o.py < cam->height);
   return o;
 }
 
 // source-image pixel -> grid_sample coordinate in [-1.1, 1.1]
-// (project_layer.py:116-126).  hm_w/hm_h are the module's heatmap_size,
-// img_w/img_h its image_size.
+// (project_layer.py:116-126)
 TEMPO_HD void tempo_pixel_to_grid(const TempoCam* cam, float px, float py,
-                                  float hm_w, float hm_h, float img_w, float img_h,
-                                  int unfused, float* gx, float* gy) {
+                                  const TempoGeom* g, int unfused, float* gx, float* gy) {
   const float wmax = cam->width > cam->height ? cam->width : cam->height;
   // torch.clamp keeps NaN; the affine below mixes px and py (0 * NaN = NaN), so
   // one NaN coordinate makes both outputs NaN: clamp NaN-blind, patch at the end
@@ -119,15 +234,18 @@ TEMPO_HD void tempo_pixel_to_grid(const TempoCam* cam, float px, float py,
   py = tempo_clamp(py, -1.0f, wmax);
   const float* t = cam->trans;
   // torch.mm(t, [x y 1]^T)
-  float ax = tempo_dot3(t[0], px, t[1], py, t[2], 1.0f, unfused);
-  float ay = tempo_dot3(t[3], px, t[4], py, t[5], 1.0f, unfused);
-  ax = (ax * hm_w) / img_w;
-  ay = (ay * hm_h) / img_h;
-  float sx = (ax / (hm_w - 1.0f)) * 2.0f - 1.0f;
-  float sy = (ay / (hm_h - 1.0f)) * 2.0f - 1.0f;
+  tempo_f2 a = tempo_dot3_2(tempo_pair(t[0], t[3]), tempo_splat(px), tempo_pair(t[1], t[4]),
+                            tempo_splat(py), tempo_pair(t[2], t[5]), tempo_splat(1.0f),
+                            unfused);
+  // xy * [w, h] / image_size;  / [w-1, h-1] * 2 - 1
+  a = tempo_div_const2(a * tempo_pair(g->hm[0], g->hm[1]), tempo_pair(g->img[0], g->img[1]),
+                       tempo_pair(g->r_img[0], g->r_img[1]));
+  a = tempo_div_const2(a, tempo_pair(g->hm1[0], g->hm1[1]),
+                       tempo_pair(g->r_hm1[0], g->r_hm1[1]));
+  a = a * tempo_splat(2.0f) - tempo_splat(1.0f);
   const float nan = __builtin_nanf("");
-  *gx = poisoned ? nan : tempo_clamp(sx, -1.1f, 1.1f);
-  *gy = poisoned ? nan : tempo_clamp(sy, -1.1f, 1.1f);
+  *gx = poisoned ? nan : tempo_clamp(a[0], -1.1f, 1.1f);
+  *gy = poisoned ? nan : tempo_clamp(a[1], -1.1f, 1.1f);
 }
 
 // grid_sample(align_corners=False) unnormalisation ((g + 1) * size - 1) / 2.

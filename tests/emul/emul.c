@@ -10,13 +10,13 @@ void emul_project(const float* cam_, const float* pts, long n, float hm_w,
                   float hm_h, float img_w, float img_h, int unf, float* pix, int* inside,
                   float* grid) {
   const TempoCam* cam = (const TempoCam*)cam_;
+  const TempoGeom geom = tempo_make_geom(hm_w, hm_h, img_w, img_h);
   for (long i = 0; i < n; i++) {
     TempoPix p = tempo_world_to_pixel(cam, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], unf);
     pix[2 * i] = p.px;
     pix[2 * i + 1] = p.py;
     inside[i] = p.inside;
-    tempo_pixel_to_grid(cam, p.px, p.py, hm_w, hm_h, img_w, img_h, unf, &grid[2 * i],
-                        &grid[2 * i + 1]);
+    tempo_pixel_to_grid(cam, p.px, p.py, &geom, unf, &grid[2 * i], &grid[2 * i + 1]);
   }
 }
 
@@ -36,6 +36,7 @@ static unsigned voxel(const float* hm, const float* cam, int V, int C, int CP,
                       int H, int W, float x, float y, float z, int root,
                       float hm_w, float hm_h, float img_w, float img_h, int unf, float* out) {
   float acc[64];
+  const TempoGeom geom = tempo_make_geom(hm_w, hm_h, img_w, img_h);
   for (int c = 0; c < C; c++) acc[c] = 0.0f;
   int cnt = 0;
   unsigned bits = 0;
@@ -44,7 +45,7 @@ static unsigned voxel(const float* hm, const float* cam, int V, int C, int CP,
     const TempoCam* cm = (const TempoCam*)(cam + v * CAM_FLOATS);
     TempoPix p = tempo_world_to_pixel(cm, x, y, z, unf);
     float gx, gy;
-    tempo_pixel_to_grid(cm, p.px, p.py, hm_w, hm_h, img_w, img_h, unf, &gx, &gy);
+    tempo_pixel_to_grid(cm, p.px, p.py, &geom, unf, &gx, &gy);
     TempoTap t = tempo_bilinear_tap(gx, gy, W, H);
     const int skip = root && !p.inside && gx == gx && gy == gy;
     cnt += p.inside;
@@ -62,7 +63,13 @@ static unsigned voxel(const float* hm, const float* cam, int V, int C, int CP,
     }
   }
   const float den = (root ? (float)cnt : (float)V) + 1e-6f;
-  for (int c = 0; c < C; c++) out[c] = tempo_nan_clamp(acc[c] / den, 0.0f, 1.0f);
+  const float rden = 1.0f / den;
+  for (int c = 0; c < C; c += 2) {
+    const tempo_f2 q = tempo_div_const2(tempo_pair(acc[c], c + 1 < C ? acc[c + 1] : 0.0f),
+                                        tempo_splat(den), tempo_splat(rden));
+    out[c] = tempo_nan_clamp(q[0], 0.0f, 1.0f);
+    if (c + 1 < C) out[c + 1] = tempo_nan_clamp(q[1], 0.0f, 1.0f);
+  }
   return bits;
 }
 
