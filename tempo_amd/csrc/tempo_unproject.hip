@@ -66,23 +66,9 @@ struct UnprojArgs {
   int total;    // NB * tiles
   int chunk;    // ceil(total / 8): contiguous run of work items per XCD label
   int mask_bytes;
-  int n_slots;  // view slots, padded to a multiple of VU
   TempoGeom geom;
   unsigned order[10];  // slot -> view in torch's summation order (one byte per slot, 255 = empty)
 };
-
-#ifndef TEMPO_OPT_SKIPA
-#define TEMPO_OPT_SKIPA 1
-#endif
-#ifndef TEMPO_OPT_SKIPB
-#define TEMPO_OPT_SKIPB 0
-#endif
-#ifndef TEMPO_OPT_BATCH
-#define TEMPO_OPT_BATCH 1
-#endif
-#ifndef TEMPO_OPT_PK
-#define TEMPO_OPT_PK 1
-#endif
 
 __device__ __forceinline__ int slot_view(const UnprojArgs& a, int slot) {
   return (int)((a.order[slot >> 2] >> ((slot & 3) * 8)) & 255u);
@@ -95,8 +81,12 @@ __device__ __forceinline__ T uniform_load(const T* p, long long i) {
   return *q;
 }
 
-__device__ __forceinline__ TempoCam load_cam(const float* cam, long long rec) {
-  const float TEMPO_AS4* q = (const float TEMPO_AS4*)(uintptr_t)(cam + rec * CAM_FLOATS);
+__device__ __forceinline__ TempoCam load_cam(const float* cam, int rec) {
+  // 64-bit multiplies run on the VALU and lose the compiler's uniformity proof
+  // (the record would then come in through vector loads): 32-bit index, pinned
+  const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(rec) * (CAM_FLOATS * 4u);
+  const float TEMPO_AS4* q =
+      (const float TEMPO_AS4*)((uintptr_t)cam + (unsigned long long)off);
   TempoCam c;
   float* d = reinterpret_cast<float*>(&c);
 #pragma unroll
@@ -134,7 +124,7 @@ __device__ __forceinline__ bool voxel_world(const UnprojArgs& a, int b, int n,
   }
 }
 
-template <int MODE, int L, int VU, int UNF>
+template <int MODE, int L, int SB, int UNF>
 __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a) {
   constexpr int VPS = 64 / L;                       // voxels per sub-step of phase B
   constexpr int NSUB = (kWaveVox + VPS - 1) / VPS;  // sub-steps per wave
@@ -147,7 +137,8 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
   const int run = bid >> 3;
   const int item = (bid & 7) * a.chunk + run;
   if (run >= a.chunk || item >= a.total) return;
-  const int b = item / a.tiles;
+  // (integer division runs on the VALU: tell the compiler the result is uniform)
+  const int b = __builtin_amdgcn_readfirstlane(item / a.tiles);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -155,10 +146,11 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
   if (n0 >= a.N) return;
   const int CPB = a.CP * 4;
 
-  // wave-private LDS: n_slots x 64 records of (4 texel offsets, 4 weights)
-  unsigned char* wbase = smem + (size_t)wave * a.n_slots * kWaveVox * 32;
+  // wave-private LDS: 2 x 64 records of (4 texel offsets, 4 weights): the view
+  // being gathered and the view being projected
+  unsigned char* wbase = smem + (size_t)wave * kWaveVox * 64;
   u32x4* s_off = reinterpret_cast<u32x4*>(wbase);
-  float4* s_wt = reinterpret_cast<float4*>(wbase + (size_t)a.n_slots * kWaveVox * 16);
+  float4* s_wt = reinterpret_cast<float4*>(wbase + (size_t)kWaveVox * 32);
 
   int frame = b;
   if (MODE == MODE_WINDOW && a.win_frame != nullptr) frame = uniform_load(a.win_frame, b);
@@ -180,159 +172,178 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
     return;
   }
 
-  // ---------------------------------------------------------------- phase A
-  {
-    float x = 0.f, y = 0.f, z = 0.f;
-    const bool have = n < a.N && voxel_world<MODE>(a, b, n, &x, &y, &z);
-    if (MODE == MODE_ROOT && a.grids != nullptr && have) {
-      float* g = a.grids + ((long long)b * a.N + n) * 3;
-      g[0] = x;
-      g[1] = y;
-      g[2] = z;
-    }
-#pragma unroll 1
-    for (int slot = 0; slot < a.n_slots; slot++) {
-      const int view = slot_view(a, slot);  // 255 = empty slot
-      u32x4 off = {kInvalid, kInvalid, kInvalid, kInvalid};
-      float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (view < a.V) {  // wave-uniform
-        const TempoCam cam = load_cam(a.cam, (long long)frame * a.V + view);
-        TempoPix p;
-        p.px = p.py = 0.f;
-        p.inside = 0;
-        bool need = false;
-        if (have) {
-          p = tempo_world_to_pixel(&cam, x, y, z, UNF);
-          // root: a view that fails the bounds test is multiplied by 0 in the
-          // reference, so its texels are never fetched -- unless a coordinate
-          // is NaN: then the reference's 0 * NaN poisons the voxel and so must we
-          need = MODE != MODE_ROOT || p.inside || p.px != p.px || p.py != p.py;
-        }
-        if (!TEMPO_OPT_SKIPA || __builtin_amdgcn_ballot_w64(need) != 0) {  // whole wave out of this view: skip
-          float gx, gy;
-          tempo_pixel_to_grid(&cam, p.px, p.py, &a.geom, UNF, &gx, &gy);
-          const TempoTap t = tempo_bilinear_tap(gx, gy, a.W, a.H);
-          // rows outside the map need no test: their byte offset is negative
-          // (wraps to > 2^31) or >= view_bytes, and the buffer load returns 0
-          const bool x0ok = (unsigned)t.x0 < (unsigned)a.W;
-          const bool x1ok = (unsigned)(t.x0 + 1) < (unsigned)a.W;
-          const bool anyrow = (unsigned)(t.y0 + 1) < (unsigned)(a.H + 1);
-          const unsigned base = (unsigned)((t.y0 * a.W + t.x0) * CPB);
-          const unsigned row = (unsigned)(a.W * CPB);
-          if (need) {
-            off.x = x0ok ? base : kInvalid;
-            off.y = x1ok ? base + CPB : kInvalid;
-            off.z = x0ok ? base + row : kInvalid;
-            off.w = x1ok ? base + row + CPB : kInvalid;
-            // bit 1: at least one texel of the footprint lies inside the map
-            off.x = (off.x & ~15u) | (((x0ok | x1ok) & anyrow) ? 2u : 0u);
-            wt = make_float4(t.nw, t.ne, t.sw, t.se);
-          }
-        }
-        if (MODE == MODE_ROOT) off.x |= (unsigned)p.inside;  // bit 0: passes the bounds test
-      }
-#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 1  // no gather traffic
-      off.x = kInvalid | (off.x & 1u); off.y = off.z = off.w = kInvalid;
-#endif
-      s_off[slot * kWaveVox + lane] = off;
-      s_wt[slot * kWaveVox + lane] = wt;
-    }
+  float x = 0.f, y = 0.f, z = 0.f;
+  const bool have = n < a.N && voxel_world<MODE>(a, b, n, &x, &y, &z);
+  if (MODE == MODE_ROOT && a.grids != nullptr && have) {
+    float* g = a.grids + ((long long)b * a.N + n) * 3;
+    g[0] = x;
+    g[1] = y;
+    g[2] = z;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  // ---------------------------------------------------------------- phase B
+  // The coordinates came in through vector loads.  Launder them through an empty
+  // asm so the waitcnt pass sees them as landed: otherwise it re-waits for
+  // "possibly pending" x/y/z at the top of every phase A with vmcnt(0), which
+  // also drains the texel fetches that phase A is meant to run under.
+  asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+
+  // phase B lane roles: L lanes per voxel, VPS voxels per sub-step
   const bool lane_on = lane < VPS * L;
   const int vq = lane / L;
   const int cq = lane - vq * L;
   const unsigned lo = (unsigned)cq * 16u;
   const char* fbase = reinterpret_cast<const char*>(a.hm + (long long)frame * a.frame_stride);
+  f32x2 acc01[NSUB], acc23[NSUB];
+  int cnt[NSUB];
+  unsigned mbits[NSUB];
+#pragma unroll
+  for (int s = 0; s < NSUB; s++) {
+    acc01[s] = tempo_splat(0.f);
+    acc23[s] = tempo_splat(0.f);
+    cnt[s] = 0;
+    mbits[s] = 0;
+  }
+
+  // phase A of one view: project this lane's voxel, park (4 offsets, 4 weights)
+  // in LDS buffer `buf`.  Returns the ballot of lanes that pass the bounds test;
+  // *active = false when no lane of the wave needs the view (nothing written).
+  auto phase_a = [&](int slot, int buf, bool* active) -> unsigned long long {
+    const int view = slot_view(a, slot);
+    const TempoCam cam = load_cam(a.cam, frame * a.V + view);
+    TempoPix p;
+    p.px = p.py = 0.f;
+    p.inside = 0;
+    bool need = false;
+    if (have) {
+      p = tempo_world_to_pixel(&cam, x, y, z, UNF);
+      // root: a view that fails the bounds test is multiplied by 0 in the
+      // reference, so its texels are never fetched -- unless a coordinate is
+      // NaN: then the reference's 0 * NaN poisons the voxel and so must we
+      need = MODE != MODE_ROOT || p.inside || p.px != p.px || p.py != p.py;
+    }
+    const unsigned long long inside_mask = __builtin_amdgcn_ballot_w64(p.inside != 0);
+    *active = __builtin_amdgcn_ballot_w64(need) != 0;
+    if (*active) {
+      u32x4 off = {kInvalid, kInvalid, kInvalid, kInvalid};
+      float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+      float gx, gy;
+      tempo_pixel_to_grid(&cam, p.px, p.py, &a.geom, UNF, &gx, &gy);
+      const TempoTap t = tempo_bilinear_tap(gx, gy, a.W, a.H);
+      // rows outside the map need no test: their byte offset is negative (wraps
+      // past 2^31) or >= view_bytes, and the buffer load returns 0 for it
+      const bool x0ok = (unsigned)t.x0 < (unsigned)a.W;
+      const bool x1ok = (unsigned)(t.x0 + 1) < (unsigned)a.W;
+      const unsigned base = (unsigned)((t.y0 * a.W + t.x0) * CPB);
+      const unsigned row = (unsigned)(a.W * CPB);
+      if (need) {
+        off.x = x0ok ? base : kInvalid;
+        off.y = x1ok ? base + CPB : kInvalid;
+        off.z = x0ok ? base + row : kInvalid;
+        off.w = x1ok ? base + row + CPB : kInvalid;
+        wt = make_float4(t.nw, t.ne, t.sw, t.se);
+      }
+#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 1  // no gather traffic
+      off.x = off.y = off.z = off.w = kInvalid;
+#endif
+#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 4  // same fetch count, all L1 hits
+      if (off.x != kInvalid) off.x = (unsigned)(lane & 15) * 64u;
+      if (off.y != kInvalid) off.y = (unsigned)(lane & 15) * 64u + 1024u;
+      if (off.z != kInvalid) off.z = (unsigned)(lane & 15) * 64u + 2048u;
+      if (off.w != kInvalid) off.w = (unsigned)(lane & 15) * 64u + 3072u;
+#endif
+      s_off[buf * kWaveVox + lane] = off;
+      s_wt[buf * kWaveVox + lane] = wt;
+    }
+    return inside_mask;
+  };
+
+  // views in torch's summation order, software-pipelined inside the wave:
+  //   issue the texel fetches of view s  ->  phase A of view s+1 (pure VALU,
+  //   runs while the fetches fly)  ->  mix view s.
+  bool act_cur = false, act_nxt = false;
+  unsigned long long in_cur = phase_a(0, 0, &act_cur), in_nxt = 0;
 #pragma unroll 1
+  for (int slot = 0; slot < a.V; slot++) {
+    const int buf = slot & 1;
+    const int view = slot_view(a, slot);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    u32x4 tex[NSUB][4];
+    if (act_cur) {
+      // descriptor from provably wave-uniform words, or hipcc wraps every fetch
+      // in a waterfall loop
+      const unsigned long long vb =
+          (unsigned long long)(uintptr_t)(fbase + (long long)view * a.view_bytes);
+      const unsigned vb_lo = __builtin_amdgcn_readfirstlane((unsigned)vb);
+      const unsigned vb_hi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          reinterpret_cast<char*>((uintptr_t)(((unsigned long long)vb_hi << 32) | vb_lo)), 0,
+          __builtin_amdgcn_readfirstlane((int)a.view_bytes), 0x00020000);
+#pragma unroll
+      for (int s = 0; s < NSUB; s++) {
+        const int vsl = s * VPS + vq;
+        const int rd = (lane_on && vsl < kWaveVox) ? vsl : 0;
+        const u32x4 o = s_off[buf * kWaveVox + rd];
+        tex[s][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.x + lo, 0, 0);
+        tex[s][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.y + lo, 0, 0);
+        tex[s][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.z + lo, 0, 0);
+        tex[s][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.w + lo, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (slot + 1 < a.V) in_nxt = phase_a(slot + 1, buf ^ 1, &act_nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (act_cur) {
+#pragma unroll
+      for (int s = 0; s < NSUB; s++) {
+        const int vsl = s * VPS + vq;
+        const int rd = (lane_on && vsl < kWaveVox) ? vsl : 0;
+        const float4 w = s_wt[buf * kWaveVox + rd];
+        const unsigned in = (unsigned)((in_cur >> rd) & 1ull);
+        cnt[s] += (int)in;
+        mbits[s] |= in << view;
+        // channels 4cq..4cq+3 as two packed pairs; same chain as
+        // tempo_bilinear_mix, then the view sum
+        const f32x2 a01 = {__uint_as_float(tex[s][0][0]), __uint_as_float(tex[s][0][1])};
+        const f32x2 a23 = {__uint_as_float(tex[s][0][2]), __uint_as_float(tex[s][0][3])};
+        const f32x2 b01 = {__uint_as_float(tex[s][1][0]), __uint_as_float(tex[s][1][1])};
+        const f32x2 b23 = {__uint_as_float(tex[s][1][2]), __uint_as_float(tex[s][1][3])};
+        const f32x2 c01 = {__uint_as_float(tex[s][2][0]), __uint_as_float(tex[s][2][1])};
+        const f32x2 c23 = {__uint_as_float(tex[s][2][2]), __uint_as_float(tex[s][2][3])};
+        const f32x2 d01 = {__uint_as_float(tex[s][3][0]), __uint_as_float(tex[s][3][1])};
+        const f32x2 d23 = {__uint_as_float(tex[s][3][2]), __uint_as_float(tex[s][3][3])};
+        const f32x2 nw = tempo_splat(w.x), ne = tempo_splat(w.y);
+        const f32x2 sw = tempo_splat(w.z), se = tempo_splat(w.w);
+        f32x2 v01 = a01 * nw, v23 = a23 * nw;
+        v01 = __builtin_elementwise_fma(b01, ne, v01);
+        v23 = __builtin_elementwise_fma(b23, ne, v23);
+        v01 = __builtin_elementwise_fma(c01, sw, v01);
+        v23 = __builtin_elementwise_fma(c23, sw, v23);
+        v01 = __builtin_elementwise_fma(d01, se, v01);
+        v23 = __builtin_elementwise_fma(d23, se, v23);
+        acc01[s] = acc01[s] + v01;
+        acc23[s] = acc23[s] + v23;
+      }
+    }
+    act_cur = act_nxt;
+    in_cur = in_nxt;
+  }
+
+  // ------------------------------------------------------------------ phase C
+  // masked mean: sum / (count + 1e-6), clamp, store.  64/L consecutive voxels x
+  // 4 channels per store instruction: runs of (64/L)*4 bytes per channel plane
+#pragma unroll
   for (int s = 0; s < NSUB; s++) {
     const int vsl = s * VPS + vq;
     const bool on = lane_on && vsl < kWaveVox && n0 + vsl < a.N;
-    const int rd = on ? vsl : 0;
-    f32x2 acc01 = {0.f, 0.f}, acc23 = {0.f, 0.f};
-    int cnt = 0;
-    unsigned mbits = 0;
-#pragma unroll 1
-    for (int g0 = 0; g0 < a.n_slots; g0 += VU) {
-      u32x4 o[VU];
-      float4 w[VU];
-      u32x4 tex[VU][4];
-      bool fetch[VU];
-#pragma unroll
-      for (int u = 0; u < VU; u++) o[u] = s_off[(g0 + u) * kWaveVox + rd];
-#pragma unroll
-      for (int u = 0; u < VU; u++) {
-        // no voxel of this sub-step sees this view: no fetch, no arithmetic
-        fetch[u] = !TEMPO_OPT_SKIPB || __builtin_amdgcn_ballot_w64(on && (o[u].x & 2u)) != 0;
-        if (fetch[u]) {
-          const int view = slot_view(a, g0 + u) & 31;
-          const char* vbase = fbase + (long long)view * a.view_bytes;
-          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-              const_cast<char*>(vbase), 0, (int)a.view_bytes, 0x00020000);
-          tex[u][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, (o[u].x & ~15u) + lo, 0, 0);
-          tex[u][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].y + lo, 0, 0);
-          tex[u][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].z + lo, 0, 0);
-          tex[u][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, o[u].w + lo, 0, 0);
-        }
-      }
-#if TEMPO_OPT_BATCH
-      // all VU*4 fetches of the sub-step are in flight before the first mix;
-      // the weights are read only now, so they do not sit in registers meanwhile
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-#pragma unroll
-      for (int u = 0; u < VU; u++) w[u] = s_wt[(g0 + u) * kWaveVox + rd];
-#pragma unroll
-      for (int u = 0; u < VU; u++) {
-        const unsigned in = o[u].x & 1u;
-        cnt += (int)in;
-        mbits |= in << (slot_view(a, g0 + u) & 31);
-        if (fetch[u]) {
-          // channels 4cq..4cq+3 as two packed pairs; same chain as
-          // tempo_bilinear_mix, then the view sum
-          const f32x2 a01 = {__uint_as_float(tex[u][0][0]), __uint_as_float(tex[u][0][1])};
-          const f32x2 a23 = {__uint_as_float(tex[u][0][2]), __uint_as_float(tex[u][0][3])};
-          const f32x2 b01 = {__uint_as_float(tex[u][1][0]), __uint_as_float(tex[u][1][1])};
-          const f32x2 b23 = {__uint_as_float(tex[u][1][2]), __uint_as_float(tex[u][1][3])};
-          const f32x2 c01 = {__uint_as_float(tex[u][2][0]), __uint_as_float(tex[u][2][1])};
-          const f32x2 c23 = {__uint_as_float(tex[u][2][2]), __uint_as_float(tex[u][2][3])};
-          const f32x2 d01 = {__uint_as_float(tex[u][3][0]), __uint_as_float(tex[u][3][1])};
-          const f32x2 d23 = {__uint_as_float(tex[u][3][2]), __uint_as_float(tex[u][3][3])};
-          const f32x2 nw = {w[u].x, w[u].x}, ne = {w[u].y, w[u].y};
-          const f32x2 sw = {w[u].z, w[u].z}, se = {w[u].w, w[u].w};
-#if TEMPO_OPT_PK
-          f32x2 v01 = a01 * nw, v23 = a23 * nw;
-          v01 = __builtin_elementwise_fma(b01, ne, v01);
-          v23 = __builtin_elementwise_fma(b23, ne, v23);
-          v01 = __builtin_elementwise_fma(c01, sw, v01);
-          v23 = __builtin_elementwise_fma(c23, sw, v23);
-          v01 = __builtin_elementwise_fma(d01, se, v01);
-          v23 = __builtin_elementwise_fma(d23, se, v23);
-          acc01 = acc01 + v01;
-          acc23 = acc23 + v23;
-#else
-          acc01.x = acc01.x + tempo_bilinear_mix(a01.x, b01.x, c01.x, d01.x, nw.x, ne.x, sw.x, se.x);
-          acc01.y = acc01.y + tempo_bilinear_mix(a01.y, b01.y, c01.y, d01.y, nw.x, ne.x, sw.x, se.x);
-          acc23.x = acc23.x + tempo_bilinear_mix(a23.x, b23.x, c23.x, d23.x, nw.x, ne.x, sw.x, se.x);
-          acc23.y = acc23.y + tempo_bilinear_mix(a23.y, b23.y, c23.y, d23.y, nw.x, ne.x, sw.x, se.x);
-#endif
-        }
-      }
-    }
-    // -------------------------------------------------------------- phase C
-    // 64/L consecutive voxels x 4 channels per store instruction: runs of
-    // (64/L)*4 bytes per channel plane, merged to full lines in L2
     if (on) {
-      // masked mean: sum / (count + 1e-6).  One IEEE reciprocal of the shared
-      // denominator, then the exact constant-divisor division on channel pairs
-      const float den = (MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f;
+      // one IEEE reciprocal of the shared denominator, then the exact
+      // constant-divisor division on channel pairs
+      const float den = (MODE == MODE_ROOT ? (float)cnt[s] : (float)a.V) + 1e-6f;
       const float rden = 1.0f / den;
-      const f32x2 q01 = tempo_div_const2(acc01, tempo_splat(den), tempo_splat(rden));
-      const f32x2 q23 = tempo_div_const2(acc23, tempo_splat(den), tempo_splat(rden));
+      const f32x2 q01 = tempo_div_const2(acc01[s], tempo_splat(den), tempo_splat(rden));
+      const f32x2 q23 = tempo_div_const2(acc23[s], tempo_splat(den), tempo_splat(rden));
       const float acc[4] = {q01.x, q01.y, q23.x, q23.y};
       float* dst = a.cubes + ((long long)b * a.C + 4 * cq) * a.N + n0 + vsl;
 #pragma unroll
@@ -345,9 +356,9 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
           dst[(long long)c * a.N] = tempo_nan_clamp(acc[c], 0.0f, 1.0f);
       if (MODE == MODE_ROOT && a.mask != nullptr && cq == 0) {
         char* m = (char*)a.mask + ((long long)b * a.N + n0 + vsl) * a.mask_bytes;
-        if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mbits;
-        else if (a.mask_bytes == 2) *(uint16_t*)m = (uint16_t)mbits;
-        else *(uint32_t*)m = mbits;
+        if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mbits[s];
+        else if (a.mask_bytes == 2) *(uint16_t*)m = (uint16_t)mbits[s];
+        else *(uint32_t*)m = mbits[s];
       }
     }
   }
@@ -407,48 +418,38 @@ __global__ __launch_bounds__(kThreads) void project_points_kernel(
 }
 
 // ------------------------------------------------------------ host helpers
-template <int MODE, int L, int VU, int UNF>
+template <int MODE, int L, int UNF>
 int launch_one(const UnprojArgs& a, hipStream_t stream) {
+#ifndef TEMPO_SB
+#define TEMPO_SB 4
+#endif
+  constexpr int SB = TEMPO_SB;  // sub-steps whose fetches are in flight together
   UnprojArgs k = a;
-  k.n_slots = ((a.V + VU - 1) / VU) * VU;
   for (int w = 0; w < 10; w++) k.order[w] = 0xffffffffu;
-  for (int sl = 0; sl < k.n_slots; sl++) {
-    const int v = tempo_view_of_slot(sl, a.V);
-    if (v >= 0) k.order[sl >> 2] = (k.order[sl >> 2] & ~(255u << ((sl & 3) * 8))) | ((unsigned)v << ((sl & 3) * 8));
+  for (int sl = 0; sl < a.V; sl++) {
+    const unsigned v = (unsigned)tempo_view_of_slot(sl, a.V);
+    k.order[sl >> 2] = (k.order[sl >> 2] & ~(255u << ((sl & 3) * 8))) | (v << ((sl & 3) * 8));
   }
-  // wave-private LDS holds every view's records; fewer waves per workgroup when
-  // many views would not fit 64 KB
-  const size_t per_wave = (size_t)k.n_slots * kWaveVox * 32;
-  int waves = (int)((64 * 1024) / per_wave);
-  if (waves < 1) return TEMPO_E_DIM;
-  if (waves > kThreads / 64) waves = kThreads / 64;
+  const int waves = kThreads / 64;
   k.tile_vox = waves * kWaveVox;
   k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
   const long long total = (long long)a.NB * k.tiles;
   if (total > 0x7fffffffLL / 8) return TEMPO_E_DIM;
   k.total = (int)total;
   k.chunk = (k.total + 7) / 8;
-  hipLaunchKernelGGL((unproject_kernel<MODE, L, VU, UNF>), dim3(8 * k.chunk),
-                     dim3(waves * 64), per_wave * waves, stream, k);
+  hipLaunchKernelGGL((unproject_kernel<MODE, L, SB, UNF>), dim3(8 * k.chunk),
+                     dim3(kThreads), (size_t)waves * kWaveVox * 64, stream, k);
   return (int)hipGetLastError();
-}
-
-template <int MODE, int L, int UNF>
-int launch_vu(const UnprojArgs& a, hipStream_t stream) {
-  // views are gathered VU at a time; pick the unroll that pads V least
-  const int pad5 = (5 - a.V % 5) % 5, pad4 = (4 - a.V % 4) % 4;
-  if (pad5 <= pad4) return launch_one<MODE, L, 5, UNF>(a, stream);
-  return launch_one<MODE, L, 4, UNF>(a, stream);
 }
 
 template <int MODE, int UNF>
 int launch_l(const UnprojArgs& a, hipStream_t stream) {
   switch (a.CP / 4) {
-    case 4: return launch_vu<MODE, 4, UNF>(a, stream);
-    case 5: return launch_vu<MODE, 5, UNF>(a, stream);
-    case 6: return launch_vu<MODE, 6, UNF>(a, stream);
-    case 7: return launch_vu<MODE, 7, UNF>(a, stream);
-    case 8: return launch_vu<MODE, 8, UNF>(a, stream);
+    case 4: return launch_one<MODE, 4, UNF>(a, stream);
+    case 5: return launch_one<MODE, 5, UNF>(a, stream);
+    case 6: return launch_one<MODE, 6, UNF>(a, stream);
+    case 7: return launch_one<MODE, 7, UNF>(a, stream);
+    case 8: return launch_one<MODE, 8, UNF>(a, stream);
     default: return TEMPO_E_PAD;
   }
 }
