@@ -32,6 +32,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaveVox = 64;                // voxels per wave
+constexpr int kWaveLds = 32 * 65 * 4;       // LDS bytes per wave: 2x64 records (4 KB) or the [CP<=32][65] output tile
 constexpr unsigned kInvalid = 0x80000000u;  // >= any view's byte size (host-checked)
 constexpr int MODE_ROOT = 0;
 constexpr int MODE_WINDOW = 1;
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
 
   // wave-private LDS: 2 x 64 records of (4 texel offsets, 4 weights): the view
   // being gathered and the view being projected
-  unsigned char* wbase = smem + (size_t)wave * kWaveVox * 64;
+  unsigned char* wbase = smem + (size_t)wave * kWaveLds;
   u32x4* s_off = reinterpret_cast<u32x4*>(wbase);
   float4* s_wt = reinterpret_cast<float4*>(wbase + (size_t)kWaveVox * 32);
 
@@ -331,36 +332,43 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
   }
 
   // ------------------------------------------------------------------ phase C
-  // masked mean: sum / (count + 1e-6), clamp, store.  64/L consecutive voxels x
-  // 4 channels per store instruction: runs of (64/L)*4 bytes per channel plane
+  // masked mean: sum / (count + 1e-6), clamp; transpose through the wave's LDS
+  // (the records are dead) so that every store instruction writes 64 consecutive
+  // voxels of one channel: 256 contiguous bytes
+  constexpr int TSTR = kWaveVox + 1;
+  float* s_out = reinterpret_cast<float*>(wbase);  // [4L][TSTR] floats <= 64*64 bytes for L <= 15
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 #pragma unroll
   for (int s = 0; s < NSUB; s++) {
     const int vsl = s * VPS + vq;
-    const bool on = lane_on && vsl < kWaveVox && n0 + vsl < a.N;
-    if (on) {
+    if (lane_on && vsl < kWaveVox) {
       // one IEEE reciprocal of the shared denominator, then the exact
       // constant-divisor division on channel pairs
       const float den = (MODE == MODE_ROOT ? (float)cnt[s] : (float)a.V) + 1e-6f;
       const float rden = 1.0f / den;
       const f32x2 q01 = tempo_div_const2(acc01[s], tempo_splat(den), tempo_splat(rden));
       const f32x2 q23 = tempo_div_const2(acc23[s], tempo_splat(den), tempo_splat(rden));
-      const float acc[4] = {q01.x, q01.y, q23.x, q23.y};
-      float* dst = a.cubes + ((long long)b * a.C + 4 * cq) * a.N + n0 + vsl;
-#pragma unroll
-      for (int c = 0; c < 4; c++)
-#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 2  // (almost) no stores
-        if (4 * cq + c < a.C && acc[c] == 123.456f)
-#else
-        if (4 * cq + c < a.C)
-#endif
-          dst[(long long)c * a.N] = tempo_nan_clamp(acc[c], 0.0f, 1.0f);
-      if (MODE == MODE_ROOT && a.mask != nullptr && cq == 0) {
+      s_out[(4 * cq + 0) * TSTR + vsl] = tempo_nan_clamp(q01.x, 0.0f, 1.0f);
+      s_out[(4 * cq + 1) * TSTR + vsl] = tempo_nan_clamp(q01.y, 0.0f, 1.0f);
+      s_out[(4 * cq + 2) * TSTR + vsl] = tempo_nan_clamp(q23.x, 0.0f, 1.0f);
+      s_out[(4 * cq + 3) * TSTR + vsl] = tempo_nan_clamp(q23.y, 0.0f, 1.0f);
+      if (MODE == MODE_ROOT && a.mask != nullptr && cq == 0 && n0 + vsl < a.N) {
         char* m = (char*)a.mask + ((long long)b * a.N + n0 + vsl) * a.mask_bytes;
         if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mbits[s];
         else if (a.mask_bytes == 2) *(uint16_t*)m = (uint16_t)mbits[s];
         else *(uint32_t*)m = mbits[s];
       }
     }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (n < a.N) {
+    float* dst = a.cubes + (long long)b * a.C * a.N + n;
+#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 2  // (almost) no stores
+    if (s_out[lane] == 123.456f)
+#endif
+    for (int ch = 0; ch < a.C; ch++) dst[(long long)ch * a.N] = s_out[ch * TSTR + lane];
   }
 }
 
@@ -438,7 +446,7 @@ int launch_one(const UnprojArgs& a, hipStream_t stream) {
   k.total = (int)total;
   k.chunk = (k.total + 7) / 8;
   hipLaunchKernelGGL((unproject_kernel<MODE, L, SB, UNF>), dim3(8 * k.chunk),
-                     dim3(kThreads), (size_t)waves * kWaveVox * 64, stream, k);
+                     dim3(kThreads), (size_t)waves * kWaveLds, stream, k);
   return (int)hipGetLastError();
 }
 
