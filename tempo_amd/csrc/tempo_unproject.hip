@@ -381,6 +381,7 @@ struct RepackArgs {
 
 constexpr int kRepackPix = 64;
 
+// Generic tile: 64 pixels, scalar loads (any HW, any alignment).
 __global__ __launch_bounds__(kThreads) void repack_kernel(const RepackArgs a) {
   __shared__ float s[TEMPO_MAX_CHANNELS][kRepackPix + 1];
   const int p0 = blockIdx.x * kRepackPix;
@@ -402,6 +403,59 @@ __global__ __launch_bounds__(kThreads) void repack_kernel(const RepackArgs a) {
       out[i] = make_float4(s[4 * cq][p], s[4 * cq + 1][p], s[4 * cq + 2][p],
                            s[4 * cq + 3][p]);
   }
+}
+
+// Wide tile: 256 pixels, 16-byte loads and stores (HW % 4 == 0, 16-byte aligned
+// planes).  A wave reads 1 KB of one channel plane per load and keeps CP/4 such
+// loads in flight; the LDS tile is channel-major with a row stride of 258 words,
+// so the b128 writes are contiguous and the transposed b32 reads of 8 pixels x 4
+// channel quads land in 32 different banks.  A block writes 256*CP*4 contiguous
+// bytes.
+constexpr int kWidePix = 256;
+constexpr int kWideStr = kWidePix + 2;
+
+template <int L>
+__global__ __launch_bounds__(kThreads) void repack_wide_kernel(const RepackArgs a) {
+  __shared__ __attribute__((aligned(16))) float s[4 * L * kWideStr];
+  const int p0 = blockIdx.x * kWidePix;
+  const int v = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* in = a.views[v] + ((long long)b * a.C_total + a.c_begin) * a.HW;
+  const int p = p0 + 4 * lane;
+  float4 r[L];
+#pragma unroll
+  for (int k = 0; k < L; k++) {
+    const int c = wave + 4 * k;
+    r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (c < a.C && p < a.HW)
+      r[k] = *reinterpret_cast<const float4*>(in + (long long)c * a.HW + p);
+  }
+#pragma unroll
+  for (int k = 0; k < L; k++) {
+    // row stride 258 words: rows start 8-byte aligned, so two b64 writes
+    float* row = s + (wave + 4 * k) * kWideStr + 4 * lane;
+    *reinterpret_cast<float2*>(row) = make_float2(r[k].x, r[k].y);
+    *reinterpret_cast<float2*>(row + 2) = make_float2(r[k].z, r[k].w);
+  }
+  __syncthreads();
+  float4* out = reinterpret_cast<float4*>(
+      a.out + (((long long)b * a.V + v) * a.HW + p0) * (4 * L));
+#pragma unroll
+  for (int j = 0; j < L; j++) {
+    // item i = tid + 256 j  ->  pixel i / L, channel quad i % L
+    const int i = tid + kThreads * j;
+    const int px = i / L, cq = i - px * L;
+    if (p0 + px < a.HW) {
+      const float* col = s + 4 * cq * kWideStr + px;
+      out[i] = make_float4(col[0], col[kWideStr], col[2 * kWideStr], col[3 * kWideStr]);
+    }
+  }
+}
+
+template <int L>
+void launch_repack_wide(const RepackArgs& a, hipStream_t stream) {
+  dim3 grid((a.HW + kWidePix - 1) / kWidePix, a.V, a.B);
+  hipLaunchKernelGGL((repack_wide_kernel<L>), grid, dim3(kThreads), 0, stream, a);
 }
 
 // ---------------------------------------------------------- project points
@@ -519,8 +573,22 @@ int tempo_repack_nhwc(const void* const* views, int V, int B, int C_total, int c
   a.out = out;
   a.V = V; a.B = B; a.C_total = C_total; a.c_begin = c_begin; a.C = C;
   a.HW = H * W; a.CP = CP;
-  dim3 grid((a.HW + kRepackPix - 1) / kRepackPix, V, B);
-  hipLaunchKernelGGL(repack_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+  bool wide = a.HW % 4 == 0 && (((long long)C_total * a.HW) % 4 == 0) &&
+              (((long long)c_begin * a.HW) % 4 == 0);
+  for (int v = 0; v < V; v++) wide = wide && (reinterpret_cast<uintptr_t>(views[v]) % 16 == 0);
+  if (wide) {
+    switch (CP / 4) {
+      case 4: launch_repack_wide<4>(a, (hipStream_t)stream); break;
+      case 5: launch_repack_wide<5>(a, (hipStream_t)stream); break;
+      case 6: launch_repack_wide<6>(a, (hipStream_t)stream); break;
+      case 7: launch_repack_wide<7>(a, (hipStream_t)stream); break;
+      case 8: launch_repack_wide<8>(a, (hipStream_t)stream); break;
+      default: return TEMPO_E_PAD;
+    }
+  } else {
+    dim3 grid((a.HW + kRepackPix - 1) / kRepackPix, V, B);
+    hipLaunchKernelGGL(repack_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+  }
   return (int)hipGetLastError();
 }
 
