@@ -69,6 +69,7 @@ struct UnprojArgs {
   int mask_bytes;
   TempoGeom geom;
   unsigned order[10];  // slot -> view in torch's summation order (one byte per slot, 255 = empty)
+  unsigned magic[2];   // floor(2^32 / dim[2]), floor(2^32 / dim[1]): voxel index -> (i0, i1, i2)
 };
 
 __device__ __forceinline__ int slot_view(const UnprojArgs& a, int slot) {
@@ -98,10 +99,15 @@ __device__ __forceinline__ TempoCam load_cam(const float* cam, int rec) {
 template <int MODE>
 __device__ __forceinline__ bool voxel_world(const UnprojArgs& a, int b, int n,
                                             float* x, float* y, float* z) {
-  const int i2 = n % a.dim[2];
-  const int t = n / a.dim[2];
-  const int i1 = t % a.dim[1];
-  const int i0 = t / a.dim[1];
+  // n = (i0 * dim[1] + i1) * dim[2] + i2.  Division by a host-known divisor:
+  // the multiply-high estimate is q or q - 1, one correction step makes it exact
+  unsigned t = __umulhi((unsigned)n, a.magic[0]);
+  unsigned r2 = (unsigned)n - t * (unsigned)a.dim[2];
+  if (r2 >= (unsigned)a.dim[2]) { r2 -= (unsigned)a.dim[2]; t++; }
+  unsigned q0 = __umulhi(t, a.magic[1]);
+  unsigned r1 = t - q0 * (unsigned)a.dim[1];
+  if (r1 >= (unsigned)a.dim[1]) { r1 -= (unsigned)a.dim[1]; q0++; }
+  const int i2 = (int)r2, i1 = (int)r1, i0 = (int)q0;
   if (MODE == MODE_ROOT) {
     *x = a.ax[0][b * a.ax_stride[0] + i0];
     *y = a.ax[1][b * a.ax_stride[1] + i1];
@@ -195,20 +201,19 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
   const unsigned lo = (unsigned)cq * 16u;
   const char* fbase = reinterpret_cast<const char*>(a.hm + (long long)frame * a.frame_stride);
   f32x2 acc01[NSUB], acc23[NSUB];
-  int cnt[NSUB];
-  unsigned mbits[NSUB];
 #pragma unroll
   for (int s = 0; s < NSUB; s++) {
     acc01[s] = tempo_splat(0.f);
     acc23[s] = tempo_splat(0.f);
-    cnt[s] = 0;
-    mbits[s] = 0;
   }
+  // views that pass the bounds test, for this lane's own voxel (phase A layout)
+  int cnt = 0;
+  unsigned mbits = 0;
 
   // phase A of one view: project this lane's voxel, park (4 offsets, 4 weights)
-  // in LDS buffer `buf`.  Returns the ballot of lanes that pass the bounds test;
-  // *active = false when no lane of the wave needs the view (nothing written).
-  auto phase_a = [&](int slot, int buf, bool* active) -> unsigned long long {
+  // in LDS buffer `buf`.  Returns false when no lane of the wave needs the view
+  // (nothing written then).
+  auto phase_a = [&](int slot, int buf) -> bool {
     const int view = slot_view(a, slot);
     const TempoCam cam = load_cam(a.cam, frame * a.V + view);
     TempoPix p;
@@ -222,27 +227,27 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
       // NaN: then the reference's 0 * NaN poisons the voxel and so must we
       need = MODE != MODE_ROOT || p.inside || p.px != p.px || p.py != p.py;
     }
-    const unsigned long long inside_mask = __builtin_amdgcn_ballot_w64(p.inside != 0);
-    *active = __builtin_amdgcn_ballot_w64(need) != 0;
-    if (*active) {
-      u32x4 off = {kInvalid, kInvalid, kInvalid, kInvalid};
-      float4 wt = make_float4(0.f, 0.f, 0.f, 0.f);
+    cnt += p.inside;
+    mbits |= (unsigned)p.inside << view;
+    const bool active = __builtin_amdgcn_ballot_w64(need) != 0;
+    if (active) {
       float gx, gy;
       tempo_pixel_to_grid(&cam, p.px, p.py, &a.geom, UNF, &gx, &gy);
       const TempoTap t = tempo_bilinear_tap(gx, gy, a.W, a.H);
       // rows outside the map need no test: their byte offset is negative (wraps
       // past 2^31) or >= view_bytes, and the buffer load returns 0 for it
-      const bool x0ok = (unsigned)t.x0 < (unsigned)a.W;
-      const bool x1ok = (unsigned)(t.x0 + 1) < (unsigned)a.W;
+      // a lane that does not need the view fetches nothing either; its weights
+      // are finite, so its (all-zero) texels mix to 0
+      const bool x0ok = need && (unsigned)t.x0 < (unsigned)a.W;
+      const bool x1ok = need && (unsigned)(t.x0 + 1) < (unsigned)a.W;
       const unsigned base = (unsigned)((t.y0 * a.W + t.x0) * CPB);
       const unsigned row = (unsigned)(a.W * CPB);
-      if (need) {
-        off.x = x0ok ? base : kInvalid;
-        off.y = x1ok ? base + CPB : kInvalid;
-        off.z = x0ok ? base + row : kInvalid;
-        off.w = x1ok ? base + row + CPB : kInvalid;
-        wt = make_float4(t.nw, t.ne, t.sw, t.se);
-      }
+      u32x4 off;
+      off.x = x0ok ? base : kInvalid;
+      off.y = x1ok ? base + CPB : kInvalid;
+      off.z = x0ok ? base + row : kInvalid;
+      off.w = x1ok ? base + row + CPB : kInvalid;
+      const float4 wt = make_float4(t.nw, t.ne, t.sw, t.se);
 #if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 1  // no gather traffic
       off.x = off.y = off.z = off.w = kInvalid;
 #endif
@@ -255,14 +260,13 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
       s_off[buf * kWaveVox + lane] = off;
       s_wt[buf * kWaveVox + lane] = wt;
     }
-    return inside_mask;
+    return active;
   };
 
   // views in torch's summation order, software-pipelined inside the wave:
   //   issue the texel fetches of view s  ->  phase A of view s+1 (pure VALU,
   //   runs while the fetches fly)  ->  mix view s.
-  bool act_cur = false, act_nxt = false;
-  unsigned long long in_cur = phase_a(0, 0, &act_cur), in_nxt = 0;
+  bool act_cur = phase_a(0, 0), act_nxt = false;
 #pragma unroll 1
   for (int slot = 0; slot < a.V; slot++) {
     const int buf = slot & 1;
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (slot + 1 < a.V) in_nxt = phase_a(slot + 1, buf ^ 1, &act_nxt);
+    if (slot + 1 < a.V) act_nxt = phase_a(slot + 1, buf ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     if (act_cur) {
 #pragma unroll
@@ -301,9 +305,6 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
         const int vsl = s * VPS + vq;
         const int rd = (lane_on && vsl < kWaveVox) ? vsl : 0;
         const float4 w = s_wt[buf * kWaveVox + rd];
-        const unsigned in = (unsigned)((in_cur >> rd) & 1ull);
-        cnt[s] += (int)in;
-        mbits[s] |= in << view;
         // channels 4cq..4cq+3 as two packed pairs; same chain as
         // tempo_bilinear_mix, then the view sum
         const f32x2 a01 = {__uint_as_float(tex[s][0][0]), __uint_as_float(tex[s][0][1])};
@@ -328,7 +329,6 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
       }
     }
     act_cur = act_nxt;
-    in_cur = in_nxt;
   }
 
   // ------------------------------------------------------------------ phase C
@@ -339,25 +339,55 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
   float* s_out = reinterpret_cast<float*>(wbase);  // [4L][TSTR] floats <= 64*64 bytes for L <= 15
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  // the denominator belongs to the voxel: one IEEE reciprocal per voxel in the
+  // phase A layout, handed to the voxel's L channel lanes through LDS
+  {
+    const float den = (MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f;
+    reinterpret_cast<float2*>(wbase)[lane] = make_float2(den, 1.0f / den);
+    if (MODE == MODE_ROOT && a.mask != nullptr && n < a.N) {
+      char* m = (char*)a.mask + ((long long)b * a.N + n) * a.mask_bytes;
+      if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mbits;
+      else if (a.mask_bytes == 2) *(uint16_t*)m = (uint16_t)mbits;
+      else *(uint32_t*)m = mbits;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float2 dr[NSUB];
+#pragma unroll
+  for (int s = 0; s < NSUB; s++) {
+    const int vsl = s * VPS + vq;
+    dr[s] = reinterpret_cast<const float2*>(wbase)[(lane_on && vsl < kWaveVox) ? vsl : 0];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // exact constant-divisor division on channel pairs; a NaN anywhere in the wave
+  // (torch.clamp keeps it) sends the whole wave through the NaN-aware clamp
+  bool odd = false;
+#pragma unroll
+  for (int s = 0; s < NSUB; s++) {
+    acc01[s] = tempo_div_const2(acc01[s], tempo_splat(dr[s].x), tempo_splat(dr[s].y));
+    acc23[s] = tempo_div_const2(acc23[s], tempo_splat(dr[s].x), tempo_splat(dr[s].y));
+    const f32x2 t = acc01[s] + acc23[s];
+    const float u = t.x + t.y;
+    odd |= u != u;
+  }
+  const bool slow = __builtin_amdgcn_ballot_w64(odd) != 0;
 #pragma unroll
   for (int s = 0; s < NSUB; s++) {
     const int vsl = s * VPS + vq;
     if (lane_on && vsl < kWaveVox) {
-      // one IEEE reciprocal of the shared denominator, then the exact
-      // constant-divisor division on channel pairs
-      const float den = (MODE == MODE_ROOT ? (float)cnt[s] : (float)a.V) + 1e-6f;
-      const float rden = 1.0f / den;
-      const f32x2 q01 = tempo_div_const2(acc01[s], tempo_splat(den), tempo_splat(rden));
-      const f32x2 q23 = tempo_div_const2(acc23[s], tempo_splat(den), tempo_splat(rden));
-      s_out[(4 * cq + 0) * TSTR + vsl] = tempo_nan_clamp(q01.x, 0.0f, 1.0f);
-      s_out[(4 * cq + 1) * TSTR + vsl] = tempo_nan_clamp(q01.y, 0.0f, 1.0f);
-      s_out[(4 * cq + 2) * TSTR + vsl] = tempo_nan_clamp(q23.x, 0.0f, 1.0f);
-      s_out[(4 * cq + 3) * TSTR + vsl] = tempo_nan_clamp(q23.y, 0.0f, 1.0f);
-      if (MODE == MODE_ROOT && a.mask != nullptr && cq == 0 && n0 + vsl < a.N) {
-        char* m = (char*)a.mask + ((long long)b * a.N + n0 + vsl) * a.mask_bytes;
-        if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mbits[s];
-        else if (a.mask_bytes == 2) *(uint16_t*)m = (uint16_t)mbits[s];
-        else *(uint32_t*)m = mbits[s];
+      float* o = s_out + (4 * cq) * TSTR + vsl;
+      if (!slow) {
+        o[0 * TSTR] = __builtin_amdgcn_fmed3f(acc01[s].x, 0.0f, 1.0f);
+        o[1 * TSTR] = __builtin_amdgcn_fmed3f(acc01[s].y, 0.0f, 1.0f);
+        o[2 * TSTR] = __builtin_amdgcn_fmed3f(acc23[s].x, 0.0f, 1.0f);
+        o[3 * TSTR] = __builtin_amdgcn_fmed3f(acc23[s].y, 0.0f, 1.0f);
+      } else {
+        o[0 * TSTR] = tempo_nan_clamp(acc01[s].x, 0.0f, 1.0f);
+        o[1 * TSTR] = tempo_nan_clamp(acc01[s].y, 0.0f, 1.0f);
+        o[2 * TSTR] = tempo_nan_clamp(acc23[s].x, 0.0f, 1.0f);
+        o[3 * TSTR] = tempo_nan_clamp(acc23[s].y, 0.0f, 1.0f);
       }
     }
   }
@@ -487,6 +517,10 @@ int launch_one(const UnprojArgs& a, hipStream_t stream) {
 #endif
   constexpr int SB = TEMPO_SB;  // sub-steps whose fetches are in flight together
   UnprojArgs k = a;
+  for (int i = 0; i < 2; i++) {
+    const unsigned long long m = 0x100000000ULL / (unsigned)a.dim[2 - i];
+    k.magic[i] = m > 0xffffffffULL ? 0xffffffffu : (unsigned)m;
+  }
   for (int w = 0; w < 10; w++) k.order[w] = 0xffffffffu;
   for (int sl = 0; sl < a.V; sl++) {
     const unsigned v = (unsigned)tempo_view_of_slot(sl, a.V);

@@ -180,9 +180,14 @@ TEMPO_HD float tempo_nan_clamp(float v, float lo, float hi) {
   return v != v ? v : r;
 }
 
-// clamp for values known not to be NaN (fminf/fmaxf drop a NaN operand)
+// clamp for values whose NaN case the caller patches itself (fminf/fmaxf drop a
+// NaN operand; the GPU's median-of-three returns the minimum then: both give lo)
 TEMPO_HD float tempo_clamp(float v, float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fmed3f(v, lo, hi);
+#else
   return fminf(fmaxf(v, lo), hi);
+#endif
 }
 
 // world point -> source-image pixel (SimpleCameraTorch.world_to_pixel)
@@ -197,8 +202,10 @@ TEMPO_HD TempoPix tempo_world_to_pixel(const TempoCam* cam, float x, float y,
   const float zc = tempo_dot3(x, R[2], y, R[5], z, R[8], unfused) + cam->T[2];
   // _X = X / X[..., 2:]   (no z > 0 test, as the reference)
   tempo_f2 n = tempo_div_shared2(xy_c, zc, tempo_rcp_est(zc));
-  // zc / zc: 1 for finite non-zero zc, NaN for 0 and +-inf
-  const float zn = (zc != 0.0f && zc - zc == 0.0f) ? 1.0f : __builtin_nanf("");
+  // the third homogeneous coordinate is zc / zc: 1 for finite non-zero zc (then
+  // 1 * K[.][2] is exact and the last step of the product below is a plain add),
+  // NaN for 0, +-inf and NaN -- which makes both pixel coordinates NaN
+  const int zbad = !(zc != 0.0f && zc - zc == 0.0f);
   if (cam->has_dist != 0.0f) {
     const float k0 = cam->kd[0], k1 = cam->kd[1], k2 = cam->kd[2];
     const tempo_f2 sq = n * n;
@@ -212,12 +219,14 @@ TEMPO_HD TempoPix tempo_world_to_pixel(const TempoCam* cam, float x, float y,
     n = n * tempo_splat(rt) + tempo_splat(r2) * tempo_pair(cam->pd[1], cam->pd[0]);
   }
   const float* K = cam->K;
-  const tempo_f2 pix = tempo_dot3_2(tempo_splat(n[0]), tempo_pair(K[0], K[3]),
-                                    tempo_splat(n[1]), tempo_pair(K[1], K[4]),
-                                    tempo_splat(zn), tempo_pair(K[2], K[5]), unfused);
+  const tempo_f2 kc0 = tempo_pair(K[0], K[3]), kc1 = tempo_pair(K[1], K[4]);
+  const tempo_f2 kc2 = tempo_pair(K[2], K[5]);
+  const tempo_f2 n0 = tempo_splat(n[0]), n1 = tempo_splat(n[1]);
+  const tempo_f2 pix =
+      unfused ? (n0 * kc0 + n1 * kc1) + kc2 : TEMPO_FMA2(n1, kc1, n0 * kc0) + kc2;
   TempoPix o;
-  o.px = pix[0];
-  o.py = pix[1];
+  o.px = zbad ? __builtin_nanf("") : pix[0];
+  o.py = zbad ? __builtin_nanf("") : pix[1];
   o.inside = (o.px >= 0.0f) & (o.py >= 0.0f) & (o.px < cam->width) & (o.py < cam->height);
   return o;
 }
@@ -242,7 +251,8 @@ TEMPO_HD void tempo_pixel_to_grid(const TempoCam* cam, float px, float py,
                        tempo_pair(g->r_img[0], g->r_img[1]));
   a = tempo_div_const2(a, tempo_pair(g->hm1[0], g->hm1[1]),
                        tempo_pair(g->r_hm1[0], g->r_hm1[1]));
-  a = a * tempo_splat(2.0f) - tempo_splat(1.0f);
+  // (a * 2) - 1: the doubling is exact, so one FMA rounds identically
+  a = TEMPO_FMA2(a, tempo_splat(2.0f), tempo_splat(-1.0f));
   const float nan = __builtin_nanf("");
   *gx = poisoned ? nan : tempo_clamp(a[0], -1.1f, 1.1f);
   *gy = poisoned ? nan : tempo_clamp(a[1], -1.1f, 1.1f);
