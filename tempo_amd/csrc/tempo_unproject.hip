@@ -32,7 +32,11 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaveVox = 64;                // voxels per wave
-constexpr int kWaveLds = 32 * 65 * 4;       // LDS bytes per wave: 2x64 records (4 KB) or the [CP<=32][65] output tile
+// LDS bytes per wave: 2 x 64 records of 32 B while gathering, then the [CP][65]
+// output tile
+constexpr int wave_lds_bytes(int L) {
+  return 4 * L * 65 * 4 > 4096 ? 4 * L * 65 * 4 : 4096;
+}
 constexpr unsigned kInvalid = 0x80000000u;  // >= any view's byte size (host-checked)
 constexpr int MODE_ROOT = 0;
 constexpr int MODE_WINDOW = 1;
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
 
   // wave-private LDS: 2 x 64 records of (4 texel offsets, 4 weights): the view
   // being gathered and the view being projected
-  unsigned char* wbase = smem + (size_t)wave * kWaveLds;
+  unsigned char* wbase = smem + (size_t)wave * wave_lds_bytes(L);
   u32x4* s_off = reinterpret_cast<u32x4*>(wbase);
   float4* s_wt = reinterpret_cast<float4*>(wbase + (size_t)kWaveVox * 32);
 
@@ -274,7 +278,58 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    u32x4 tex[NSUB][4];
+    // SB sub-steps' fetches (4 * SB registers-quads) are in flight together; the
+    // first group flies under the projection of the next view
+    constexpr int G = SB < NSUB ? SB : NSUB;
+    u32x4 tex[G][4];
+    __amdgpu_buffer_rsrc_t rs;
+    auto fetch = [&](int s0) {
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const int s = s0 + g;
+        if (s < NSUB) {
+          const int vsl = s * VPS + vq;
+          const int rd = (lane_on && vsl < kWaveVox) ? vsl : 0;
+          const u32x4 o = s_off[buf * kWaveVox + rd];
+          tex[g][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.x + lo, 0, 0);
+          tex[g][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.y + lo, 0, 0);
+          tex[g][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.z + lo, 0, 0);
+          tex[g][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.w + lo, 0, 0);
+        }
+      }
+    };
+    auto mix = [&](int s0) {
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const int s = s0 + g;
+        if (s < NSUB) {
+          const int vsl = s * VPS + vq;
+          const int rd = (lane_on && vsl < kWaveVox) ? vsl : 0;
+          const float4 w = s_wt[buf * kWaveVox + rd];
+          // channels 4cq..4cq+3 as two packed pairs; same chain as
+          // tempo_bilinear_mix, then the view sum
+          const f32x2 a01 = {__uint_as_float(tex[g][0][0]), __uint_as_float(tex[g][0][1])};
+          const f32x2 a23 = {__uint_as_float(tex[g][0][2]), __uint_as_float(tex[g][0][3])};
+          const f32x2 b01 = {__uint_as_float(tex[g][1][0]), __uint_as_float(tex[g][1][1])};
+          const f32x2 b23 = {__uint_as_float(tex[g][1][2]), __uint_as_float(tex[g][1][3])};
+          const f32x2 c01 = {__uint_as_float(tex[g][2][0]), __uint_as_float(tex[g][2][1])};
+          const f32x2 c23 = {__uint_as_float(tex[g][2][2]), __uint_as_float(tex[g][2][3])};
+          const f32x2 d01 = {__uint_as_float(tex[g][3][0]), __uint_as_float(tex[g][3][1])};
+          const f32x2 d23 = {__uint_as_float(tex[g][3][2]), __uint_as_float(tex[g][3][3])};
+          const f32x2 nw = tempo_splat(w.x), ne = tempo_splat(w.y);
+          const f32x2 sw = tempo_splat(w.z), se = tempo_splat(w.w);
+          f32x2 v01 = a01 * nw, v23 = a23 * nw;
+          v01 = __builtin_elementwise_fma(b01, ne, v01);
+          v23 = __builtin_elementwise_fma(b23, ne, v23);
+          v01 = __builtin_elementwise_fma(c01, sw, v01);
+          v23 = __builtin_elementwise_fma(c23, sw, v23);
+          v01 = __builtin_elementwise_fma(d01, se, v01);
+          v23 = __builtin_elementwise_fma(d23, se, v23);
+          acc01[s] = acc01[s] + v01;
+          acc23[s] = acc23[s] + v23;
+        }
+      }
+    };
     if (act_cur) {
       // descriptor from provably wave-uniform words, or hipcc wraps every fetch
       // in a waterfall loop
@@ -282,50 +337,22 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
           (unsigned long long)(uintptr_t)(fbase + (long long)view * a.view_bytes);
       const unsigned vb_lo = __builtin_amdgcn_readfirstlane((unsigned)vb);
       const unsigned vb_hi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      rs = __builtin_amdgcn_make_buffer_rsrc(
           reinterpret_cast<char*>((uintptr_t)(((unsigned long long)vb_hi << 32) | vb_lo)), 0,
           __builtin_amdgcn_readfirstlane((int)a.view_bytes), 0x00020000);
-#pragma unroll
-      for (int s = 0; s < NSUB; s++) {
-        const int vsl = s * VPS + vq;
-        const int rd = (lane_on && vsl < kWaveVox) ? vsl : 0;
-        const u32x4 o = s_off[buf * kWaveVox + rd];
-        tex[s][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.x + lo, 0, 0);
-        tex[s][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.y + lo, 0, 0);
-        tex[s][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.z + lo, 0, 0);
-        tex[s][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.w + lo, 0, 0);
-      }
+      fetch(0);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (slot + 1 < a.V) act_nxt = phase_a(slot + 1, buf ^ 1);
     __builtin_amdgcn_sched_barrier(0);
     if (act_cur) {
+      mix(0);
 #pragma unroll
-      for (int s = 0; s < NSUB; s++) {
-        const int vsl = s * VPS + vq;
-        const int rd = (lane_on && vsl < kWaveVox) ? vsl : 0;
-        const float4 w = s_wt[buf * kWaveVox + rd];
-        // channels 4cq..4cq+3 as two packed pairs; same chain as
-        // tempo_bilinear_mix, then the view sum
-        const f32x2 a01 = {__uint_as_float(tex[s][0][0]), __uint_as_float(tex[s][0][1])};
-        const f32x2 a23 = {__uint_as_float(tex[s][0][2]), __uint_as_float(tex[s][0][3])};
-        const f32x2 b01 = {__uint_as_float(tex[s][1][0]), __uint_as_float(tex[s][1][1])};
-        const f32x2 b23 = {__uint_as_float(tex[s][1][2]), __uint_as_float(tex[s][1][3])};
-        const f32x2 c01 = {__uint_as_float(tex[s][2][0]), __uint_as_float(tex[s][2][1])};
-        const f32x2 c23 = {__uint_as_float(tex[s][2][2]), __uint_as_float(tex[s][2][3])};
-        const f32x2 d01 = {__uint_as_float(tex[s][3][0]), __uint_as_float(tex[s][3][1])};
-        const f32x2 d23 = {__uint_as_float(tex[s][3][2]), __uint_as_float(tex[s][3][3])};
-        const f32x2 nw = tempo_splat(w.x), ne = tempo_splat(w.y);
-        const f32x2 sw = tempo_splat(w.z), se = tempo_splat(w.w);
-        f32x2 v01 = a01 * nw, v23 = a23 * nw;
-        v01 = __builtin_elementwise_fma(b01, ne, v01);
-        v23 = __builtin_elementwise_fma(b23, ne, v23);
-        v01 = __builtin_elementwise_fma(c01, sw, v01);
-        v23 = __builtin_elementwise_fma(c23, sw, v23);
-        v01 = __builtin_elementwise_fma(d01, se, v01);
-        v23 = __builtin_elementwise_fma(d23, se, v23);
-        acc01[s] = acc01[s] + v01;
-        acc23[s] = acc23[s] + v23;
+      for (int s0 = G; s0 < NSUB; s0 += G) {
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(s0);
+        __builtin_amdgcn_sched_barrier(0);
+        mix(s0);
       }
     }
     act_cur = act_nxt;
@@ -512,10 +539,14 @@ __global__ __launch_bounds__(kThreads) void project_points_kernel(
 // ------------------------------------------------------------ host helpers
 template <int MODE, int L, int UNF>
 int launch_one(const UnprojArgs& a, hipStream_t stream) {
-#ifndef TEMPO_SB
-#define TEMPO_SB 4
+#ifndef TEMPO_SB_ROOT
+#define TEMPO_SB_ROOT 8
 #endif
-  constexpr int SB = TEMPO_SB;  // sub-steps whose fetches are in flight together
+#ifndef TEMPO_SB_WINDOW
+#define TEMPO_SB_WINDOW 1
+#endif
+  // sub-steps whose fetches are in flight together (8 = all of a view's)
+  constexpr int SB = MODE == MODE_ROOT ? TEMPO_SB_ROOT : TEMPO_SB_WINDOW;
   UnprojArgs k = a;
   for (int i = 0; i < 2; i++) {
     const unsigned long long m = 0x100000000ULL / (unsigned)a.dim[2 - i];
@@ -534,7 +565,7 @@ int launch_one(const UnprojArgs& a, hipStream_t stream) {
   k.total = (int)total;
   k.chunk = (k.total + 7) / 8;
   hipLaunchKernelGGL((unproject_kernel<MODE, L, SB, UNF>), dim3(8 * k.chunk),
-                     dim3(kThreads), (size_t)waves * kWaveLds, stream, k);
+                     dim3(kThreads), (size_t)waves * wave_lds_bytes(L), stream, k);
   return (int)hipGetLastError();
 }
 
