@@ -47,6 +47,9 @@ def build_root(name, device='cpu', full=None):
     cfg = _cfg(spec['cfg'])
     if 'hm_size' in spec:
         cfg['heatmap_size'], cfg['image_size'] = spec['hm_size'], spec['img_size']
+    for key in ('num_views', 'num_joints'):  # ring-camera configs only
+        if key in spec:
+            cfg[key] = spec[key]
     B, seed = spec['B'], spec['seed']
     cams = _cams(spec['cfg'], cfg, seed)
     centers, scales, cameras = S.frame_meta(cams, B, cfg['raw_size'], cfg['image_size'])
@@ -72,6 +75,9 @@ def build_window(name, device='cpu', full=None):
     cfg = _cfg(spec['cfg'])
     if 'hm_size' in spec:
         cfg['heatmap_size'], cfg['image_size'] = spec['hm_size'], spec['img_size']
+    for key in ('num_views', 'num_joints'):  # ring-camera configs only
+        if key in spec:
+            cfg[key] = spec[key]
     B, seed = spec['B'], spec['seed']
     space = spec.get('space', cfg['space_size'])
     sub = spec.get('sub', cfg['sub_space_size'])
