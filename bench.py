@@ -175,6 +175,29 @@ def cpu_baseline(args):
     }
 
 
+def measured_traffic(args, wl):
+    """HBM bytes per launch of the dominant kernel from the committed PMC pass of this very
+    workload (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs: tools/profile_round.sh).
+    bench.py cannot collect counters about itself, so the number comes from profiles/ and is
+    reported only for the configuration that was profiled.  FETCH_SIZE is in KB and counts
+    64 B per fabric request; this kernel's texel fetches are 64-byte requests, so it is taken at
+    face value (calibration: profiles/r01/fetch_size_calibration.txt)."""
+    import csv
+    tag = 'root' if args.workload == 'root' else 'window'
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01',
+                        tag + '_pmc_summary.csv')
+    if args.batch != 32 or (tag == 'window' and args.proposals != 10) or not os.path.exists(path):
+        return None, None
+    vals = {}
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row['kernel'].startswith('unproject_kernel'):
+                vals[row['counter']] = float(row['mean_per_dispatch'])
+    if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
+        return None, None
+    return int((vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), 'profiles/r01/' + tag + '_pmc_summary.csv'
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -227,6 +250,7 @@ def main():
     r_ms = sum(c.elapsed_time(d) for c, d in rp) / len(rp)
 
     if rank == 0:
+        traffic, traffic_src = measured_traffic(args, wl)
         ms_step = elapsed / args.steps * 1e3
         achieved = wl.kernel_bytes / (k_ms * 1e-3) / 1e9
         line = {
@@ -242,7 +266,8 @@ def main():
                        'partition': f'frames x proposals over {world} rank(s), no collective'},
             'roofline': {
                 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+                'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                'traffic_source': traffic_src,
                 'kernel': wl.kernel_name, 'kernel_ms': round(k_ms, 4),
                 'algorithmic_bytes': wl.kernel_bytes},
             'repack_ms': round(r_ms, 4),

@@ -8,20 +8,22 @@
 //
 // Kernel structure.  One wave = 64 consecutive voxels of one batch item / window
 // and is autonomous (no workgroup barrier; a 256-thread workgroup is four such
-// waves sharing an LDS allocation):
-//   phase A  lane = voxel.  For each view of the current group (VU views): the
-//            camera record comes in through scalar loads (wave-uniform), the
-//            lane projects, distorts, bounds-tests and turns the sample point
-//            into 4 texel byte-offsets + 4 bilinear weights, parked in LDS.
-//   phase B  L lanes per voxel (lane cq owns channels 4cq..4cq+3), 64/L voxels
-//            per sub-step: per view one 16-byte buffer_load per texel, so L
-//            lanes read one texel's CP*4 contiguous bytes; texels outside the
-//            map and views failing the bounds test carry an out-of-range
-//            offset, which the buffer hardware answers with 0 and no memory
-//            traffic.  Bilinear mix and the view sum run in registers in
-//            torch's summation order.
-//   phase C  normalise, clamp, transpose through LDS, store 256 contiguous
-//            bytes per channel.
+// waves sharing an LDS allocation).  Per view, in torch's summation order:
+//   project   lane = voxel.  The camera record comes in through scalar loads
+//             (wave-uniform); the lane projects, distorts, bounds-tests and turns
+//             the sample point into 4 texel byte-offsets + 4 bilinear weights,
+//             parked in LDS (double-buffered over views).  Count and bitmap of
+//             the views that pass the bounds test stay in this layout.
+//   fetch     L lanes per voxel (lane cq owns channels 4cq..4cq+3), 64/L voxels
+//             per sub-step: one 16-byte buffer_load per texel, so L lanes read
+//             one texel's CP*4 contiguous bytes; texels outside the map and
+//             lanes that do not need the view carry an out-of-range offset,
+//             which the buffer hardware answers with 0 and no memory traffic.
+//   mix       bilinear mix (packed fp32) and view sum in registers.
+//   The loop is software-pipelined inside the wave: fetches of view s fly under
+//   the projection of view s+1.
+// Then: normalise (exact division by count + 1e-6), clamp, transpose through
+// LDS, store 256 contiguous bytes per channel plane and instruction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
