@@ -153,25 +153,33 @@ def cpu_baseline(args):
     centers, scales, cameras = S.frame_meta(cams, 1, cfg['raw_size'], cfg['image_size'])
     layer = O.ProjectLayer(cfg['image_size'], cfg['heatmap_size'], 'mean')
     cores = min(os.cpu_count() or 1, 16)  # the GPU box grants a 16-core share
-    torch.set_num_threads(cores)
     call = lambda: layer(fms, cfg['space_size'], [cfg['space_center']], cfg['cube_size'],
                          centers, scales, cameras)
-    for _ in range(3):
-        call()
-    times = []
-    t_end = time.perf_counter() + 15.0
-    while len(times) < 10 or (time.perf_counter() < t_end and len(times) < 200):
-        t0 = time.perf_counter()
-        call()
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
+
+    def median_call(threads, budget_s, max_calls):
+        torch.set_num_threads(threads)
+        for _ in range(3):
+            call()
+        times = []
+        t_end = time.perf_counter() + budget_s
+        while len(times) < 10 or (time.perf_counter() < t_end and len(times) < max_calls):
+            t0 = time.perf_counter()
+            call()
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        return times[len(times) // 2], len(times)
+
     n = cfg['cube_size'][0] * cfg['cube_size'][1] * cfg['cube_size'][2]
+    med, calls = median_call(cores, 12.0, 200)
+    med1, calls1 = median_call(1, 8.0, 50)  # also at one thread
     return {
         'value': round(n * V / med / 1e9, 6), 'unit': 'Gsamp/s', 'cores': cores,
         'kind': 'port',
         'sample': f'oracle ProjectLayer, Panoptic cam5 root 80x80x20, B=1 (640000 samples/call), '
-                  f'median of {len(times)} calls, {med * 1e3:.1f} ms/call',
+                  f'median of {calls} calls, {med * 1e3:.1f} ms/call',
+        'value_1_thread': round(n * V / med1 / 1e9, 6),
+        'sample_1_thread': f'same call, torch.set_num_threads(1), median of {calls1} calls, '
+                           f'{med1 * 1e3:.1f} ms/call',
     }
 
 

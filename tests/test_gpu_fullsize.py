@@ -157,3 +157,36 @@ def test_zslabs_reassemble(gpu_device):
             slabs = [layer.get_voxel(*dcase['args'], zslab=(r * step, (r + 1) * step))[0]
                      for r in range(world)]
             assert _same(torch.cat(slabs, dim=-1), full)
+
+
+def test_config5_dense_128_cubed_10_views(gpu_device):
+    """BASELINE configs[4] at full size on one device: 10 views, 15 joints, 128^3 grid;
+    the oracle on the whole grid, and the 8 z-slabs of the 8-GPU run reassembled."""
+    spec = dict(cfg='panoptic', B=1, cube=[128, 128, 128], hm='noise', seed=105, num_views=10)
+    case, dcase, layer = _root_pair(spec, gpu_device)
+    ref_layer = O.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    ref, _ = ref_layer(*case['args'])
+    layer.materialize_grids = False
+    with torch.no_grad():
+        full, _ = layer(*dcase['args'])
+        assert _maxabs(full.cpu(), ref) <= TOL
+        assert torch.equal(layer.last_mask.cpu().to(torch.int32).view(-1),
+                           _bits(ref_layer.last_bounding).view(-1))
+        slabs = [layer.get_voxel(*dcase['args'], zslab=(16 * r, 16 * r + 16))[0] for r in range(8)]
+    assert _same(torch.cat(slabs, dim=-1), full)
+
+
+def test_config4_h36m_384_maps(gpu_device):
+    """BASELINE configs[3] geometry at the reference's map size: H36M 4 cameras, 17 joints,
+    384x384 heatmaps and image, 64^3 windows in the 8000x8000x2000 space."""
+    import tempo_amd
+    spec = dict(cfg='h36m', B=2, sub_cube=[64, 64, 64], hm='noise', seed=303, invalid_every=0,
+                hm_size=[384, 384], img_size=[384, 384])
+    case = cases.build_window(None, full=spec)
+    ref_layer = O.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    ref, ref_off = ref_layer(*case['args'])
+    layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    with torch.no_grad():
+        got, off = layer(*cases.to_device(case, gpu_device)['args'])
+    assert _maxabs(got.cpu(), ref) <= TOL
+    assert torch.equal(off.cpu(), ref_off)
