@@ -38,6 +38,12 @@ def parse():
     ap.add_argument('--workload', default='root', choices=['root', 'window'])
     ap.add_argument('--batch', type=int, default=32, help='frames per GPU')
     ap.add_argument('--proposals', type=int, default=10, help='window workload only')
+    ap.add_argument('--calibrations', type=int, default=1,
+                    help='distinct camera calibrations in the batch (recordings the frames '
+                         'come from); frames of one calibration are consecutive')
+    ap.add_argument('--no-share', action='store_true',
+                    help='project every frame for itself even when calibrations repeat')
+    ap.add_argument('--group-max', type=int, default=None, help='frames per shared projection')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
 
@@ -51,10 +57,17 @@ def make_inputs(args, dev, seed):
     w, h = cfg['heatmap_size']
     g = torch.Generator(device=dev).manual_seed(seed)
     fms = [torch.rand(B, J, h, w, device=dev, generator=g) for _ in range(V)]
-    cams = S.ring_cameras(V, seed=seed, target=cfg['space_center'])
-    centers, scales, cameras = S.frame_meta(cams, B, cfg['raw_size'], cfg['image_size'])
-    cam = pack_cameras(centers, scales, cameras, cfg['image_size']).to(dev)
-    return cfg, fms, cam, (centers, scales, cameras)
+    ncal = max(1, min(args.calibrations, B))
+    centers, scales, cameras = [], [], []
+    for k in range(ncal):
+        cams = S.ring_cameras(V, seed=seed + 1000 * k, target=cfg['space_center'])
+        nb = (B * (k + 1)) // ncal - (B * k) // ncal
+        c, s, m = S.frame_meta(cams, nb, cfg['raw_size'], cfg['image_size'])
+        centers += c
+        scales += s
+        cameras += m
+    cam_host = pack_cameras(centers, scales, cameras, cfg['image_size'])
+    return cfg, fms, cam_host.to(dev), cam_host
 
 
 class RootWorkload:
@@ -63,9 +76,14 @@ class RootWorkload:
     def __init__(self, args, dev, seed):
         from tempo_amd import ops, project_layer as PL
         self.ops = ops
-        self.cfg, self.fms, self.cam, _ = make_inputs(args, dev, seed)
+        self.cfg, self.fms, self.cam, cam_host = make_inputs(args, dev, seed)
         cfg = self.cfg
         self.B, self.V, self.J = args.batch, cfg['num_views'], cfg['num_joints']
+        # frames with bit-identical camera records share one projection per voxel
+        self.groups = None
+        if not args.no_share:
+            g = ops.share_groups(ops.camera_keys(cam_host), args.group_max)
+            self.groups = None if g is None else g.to(dev)
         self.axes = [(PL._base_axis(cfg['space_size'][i], cfg['cube_size'][i]) +
                       cfg['space_center'][i]).to(dev) for i in range(3)]
         X, Y, Z = cfg['cube_size']
@@ -78,7 +96,8 @@ class RootWorkload:
         # volume written once + every heatmap element read once + cameras
         self.kernel_bytes = (4 * self.B * self.J * self.N + 4 * self.B * self.V * self.J * h * w
                              + 128 * self.B * self.V)
-        self.kernel_name = 'unproject_kernel<ROOT>'
+        self.kernel_name = ('unproject_group_kernel<ROOT>' if self.groups is not None
+                            else 'unproject_kernel<ROOT>')
 
     def repack(self):
         self.ops.repack_nhwc(self.fms, out=self.hm)
@@ -86,7 +105,7 @@ class RootWorkload:
     def kernel(self):
         self.ops.unproject_root(self.hm, self.cam, self.axes, self.J,
                                 self.cfg['heatmap_size'], self.cfg['image_size'],
-                                out=self.out)
+                                out=self.out, groups=self.groups)
 
     def step(self):
         self.repack()
@@ -199,7 +218,7 @@ def measured_traffic(args, wl):
     vals = {}
     with open(path) as f:
         for row in csv.DictReader(f):
-            if row['kernel'].startswith('unproject_kernel'):
+            if row['kernel'].startswith(wl.kernel_name.split('<')[0] + '<'):
                 vals[row['counter']] = float(row['mean_per_dispatch'])
     if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
         return None, None
@@ -269,7 +288,10 @@ def main():
             'ms_per_step': round(ms_step, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': wl.name, 'frames_per_gpu': args.batch, 'views': wl.V,
+            'config': {'workload': wl.name, 'frames_per_gpu': args.batch,
+                       'calibrations_per_batch': max(1, min(args.calibrations, args.batch)),
+                       'shared_projection': getattr(wl, 'groups', None) is not None,
+                       'views': wl.V,
                        'joints': wl.J, 'samples_per_step_per_gpu': wl.samples,
                        'partition': f'frames x proposals over {world} rank(s), no collective'},
             'roofline': {

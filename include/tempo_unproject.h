@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define TEMPO_ABI_VERSION 1
+#define TEMPO_ABI_VERSION 2
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
@@ -103,6 +103,25 @@ int tempo_unproject_root(const float* hm, const float* cam, const float* ax_x,
                          float hm_h, float img_w, float img_h, int mm_unfused,
                          void* stream);
 
+/* tempo_unproject_root for a batch in which runs of consecutive items share one
+ * calibration and one grid -- the frames of one recording; the reference
+ * re-projects the grid for every item (project_layer.py:80-111).
+ *   groups : DEVICE int32 [num_groups, 2] = (first item, count); the groups
+ *            partition [0, B).  The caller guarantees that the items of a group
+ *            have bit-identical camera records cam[item] and, with ax_batched,
+ *            identical axes; only their heatmaps (and live flags) differ.  The
+ *            projection then runs once per group and voxel; results are
+ *            bit-identical to tempo_unproject_root.  NULL / 0 = no sharing. */
+int tempo_unproject_root_grouped(const float* hm, const float* cam,
+                                 const float* ax_x, const float* ax_y,
+                                 const float* ax_z, int ax_batched,
+                                 const uint8_t* live, float* cubes, float* grids,
+                                 void* mask, int mask_bytes, int B, int V, int C,
+                                 int CP, int H, int W, int X, int Y, int Z,
+                                 float hm_w, float hm_h, float img_w, float img_h,
+                                 int mm_unfused, const int32_t* groups,
+                                 int num_groups, void* stream);
+
 /* Per-person window unprojection: ProjectLayerWithMask.get_voxel +
  * project_grid, project_layer.py:225-378 (agg_method == 'mean').  Only the
  * window's own voxels are projected (the reference projects the whole fine
@@ -124,6 +143,22 @@ int tempo_unproject_window(const float* hm, const float* cam,
                            int FZ, int VX, int VY, int VZ, float hm_w,
                            float hm_h, float img_w, float img_h, int mm_unfused,
                            void* stream);
+
+/* tempo_unproject_window for runs of consecutive windows that share tl/start/end
+ * and the camera records of their frames -- the T timesteps of one proposal
+ * (tempo_pose.py:145-156 calls the layer once per timestep with the same
+ * candidate).  groups as in tempo_unproject_root_grouped, partitioning [0, NW). */
+int tempo_unproject_window_grouped(const float* hm, const float* cam,
+                                   const int32_t* win_frame, const float* fx,
+                                   const float* fy, const float* fz,
+                                   const int32_t* tl, const int32_t* start,
+                                   const int32_t* end, const uint8_t* live,
+                                   float* cubes, int NW, int F, int V, int C,
+                                   int CP, int H, int W, int FX, int FY, int FZ,
+                                   int VX, int VY, int VZ, float hm_w, float hm_h,
+                                   float img_w, float img_h, int mm_unfused,
+                                   const int32_t* groups, int num_groups,
+                                   void* stream);
 
 /* Projection only, for parity checks of the coordinate chain
  * (SimpleCameraTorch.world_to_pixel + project_layer.py:113-126):

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TEMPO_LIB') or os.path.join(_HERE, 'lib', 'libtempo_unproject.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_void_p, _c_int, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
@@ -24,6 +24,12 @@ SIGNATURES = {
                              [_c_int] * 10 + [_c_float] * 4 + [_c_int, _c_void_p]),
     'tempo_unproject_window': (_c_int, [_c_void_p] * 11 + [_c_int] * 13 +
                                [_c_float] * 4 + [_c_int, _c_void_p]),
+    'tempo_unproject_root_grouped': (_c_int, [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 4 +
+                                     [_c_int] * 10 + [_c_float] * 4 +
+                                     [_c_int, _c_void_p, _c_int, _c_void_p]),
+    'tempo_unproject_window_grouped': (_c_int, [_c_void_p] * 11 + [_c_int] * 13 +
+                                       [_c_float] * 4 +
+                                       [_c_int, _c_void_p, _c_int, _c_void_p]),
     'tempo_project_points': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int] +
                              [_c_float] * 4 + [_c_int] + [_c_void_p] * 4),
 }

@@ -27,6 +27,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/tempo_unproject.h"
 #include "unproject_math.h"
 
@@ -74,6 +76,9 @@ struct UnprojArgs {
   int chunk;    // ceil(total / 8): contiguous run of work items per XCD label
   int mask_bytes;
   TempoGeom geom;
+  const int32_t* groups;  // grouped launch: [NG][2] = (first item, count), or nullptr
+  int NG;
+  int wave_lds;  // grouped launch: LDS bytes per wave
   unsigned order[10];  // slot -> view in torch's summation order (one byte per slot, 255 = empty)
   unsigned magic[2];   // floor(2^32 / dim[2]), floor(2^32 / dim[1]): voxel index -> (i0, i1, i2)
 };
@@ -87,6 +92,15 @@ template <typename T>
 __device__ __forceinline__ T uniform_load(const T* p, long long i) {
   const T TEMPO_AS4* q = (const T TEMPO_AS4*)(uintptr_t)(p + i);
   return *q;
+}
+
+// one byte, wave-uniform: the scalar unit has no byte loads (a byte read would
+// go through the vector memory pipe and its wait would drain the texel fetches
+// in flight), so read the aligned word that holds it
+__device__ __forceinline__ unsigned uniform_load_u8(const uint8_t* p, long long i) {
+  const uintptr_t addr = (uintptr_t)(p + i);
+  const unsigned TEMPO_AS4* q = (const unsigned TEMPO_AS4*)(addr & ~(uintptr_t)3);
+  return (*q >> (unsigned)((addr & 3) * 8)) & 255u;
 }
 
 __device__ __forceinline__ TempoCam load_cam(const float* cam, int rec) {
@@ -167,7 +181,7 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
 
   int frame = b;
   if (MODE == MODE_WINDOW && a.win_frame != nullptr) frame = uniform_load(a.win_frame, b);
-  const bool dead = (a.live != nullptr && uniform_load(a.live, b) == 0) ||
+  const bool dead = (a.live != nullptr && uniform_load_u8(a.live, b) == 0) ||
                     (unsigned)frame >= (unsigned)a.F;
   const int n = n0 + lane;  // phase A: this lane's voxel
   if (dead) {
@@ -219,8 +233,22 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
   // phase A of one view: project this lane's voxel, park (4 offsets, 4 weights)
   // in LDS buffer `buf`.  Returns false when no lane of the wave needs the view
   // (nothing written then).
+#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 6  // projection of view 0 reused by every view
+  u32x4 abl_off = {0, 0, 0, 0};
+  float4 abl_wt = make_float4(0.f, 0.f, 0.f, 0.f);
+  bool abl_act = false;
+#endif
   auto phase_a = [&](int slot, int buf) -> bool {
     const int view = slot_view(a, slot);
+#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 6
+    if (slot > 0) {
+      if (abl_act) {
+        s_off[buf * kWaveVox + lane] = abl_off;
+        s_wt[buf * kWaveVox + lane] = abl_wt;
+      }
+      return abl_act;
+    }
+#endif
     const TempoCam cam = load_cam(a.cam, frame * a.V + view);
     TempoPix p;
     p.px = p.py = 0.f;
@@ -265,7 +293,14 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
 #endif
       s_off[buf * kWaveVox + lane] = off;
       s_wt[buf * kWaveVox + lane] = wt;
+#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 6
+      abl_off = off;
+      abl_wt = wt;
+#endif
     }
+#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 6
+    abl_act = active;
+#endif
     return active;
   };
 
@@ -431,6 +466,293 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
   }
 }
 
+// ------------------------------------------------------------ grouped launch
+// Batch items (root) / windows that share one calibration and one voxel lattice
+// -- the frames of one sequence, the T timesteps of one proposal -- project to
+// the same texel footprints.  One wave = 64 voxels x the items of one group:
+//   project   once per view, as in unproject_kernel; the footprint is parked in
+//             LDS as a 16-byte record (top-left texel byte offset, edge flags,
+//             the two bilinear fractions) for ALL views;
+//   per item  fetch + mix over the views the wave needs, reading the records:
+//             pure gather, two half-views of fetches in flight, the next
+//             half-view (or the next item's first) issued before each mix;
+//             then normalise, clamp, transpose through LDS and store, with the
+//             reciprocal of the view count computed once per group.
+// The arithmetic per (voxel, view, item) is the one of unproject_kernel, so the
+// results are bit-identical to an ungrouped launch.
+struct __align__(16) GroupRec {
+  unsigned base;   // byte offset of texel (x0, y0) in the view's map (may wrap: outside)
+  unsigned flags;  // bit 0: column x0 inside the map and needed, bit 1: column x0 + 1
+  float w, n;      // ix - floor(ix), iy - floor(iy)
+};
+
+constexpr int group_wave_lds(int V, int L) {
+  return V * kWaveVox * (int)sizeof(GroupRec) + kWaveVox * 8 + 4 * L * (kWaveVox + 1) * 4;
+}
+
+template <int MODE, int L, int UNF>
+__global__ __launch_bounds__(kThreads) void unproject_group_kernel(const UnprojArgs a) {
+  constexpr int VPS = 64 / L;
+  constexpr int NSUB = (kWaveVox + VPS - 1) / VPS;
+  constexpr int G = (NSUB + 1) / 2;  // sub-steps per half view
+  extern __shared__ __align__(16) unsigned char smem[];
+
+  const int bid = blockIdx.x;
+  const int run = bid >> 3;
+  const int item = (bid & 7) * a.chunk + run;  // XCD-aware order, as unproject_kernel
+  if (run >= a.chunk || item >= a.total) return;
+  const int grp = __builtin_amdgcn_readfirstlane(item / a.tiles);
+  const int first = uniform_load(a.groups, 2 * grp);
+  const int nfr = uniform_load(a.groups, 2 * grp + 1);
+  if (first < 0 || nfr <= 0 || first > a.NB - nfr) return;  // malformed table: touch nothing
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = (item - grp * a.tiles) * a.tile_vox + wave * kWaveVox;
+  if (n0 >= a.N) return;
+  const int n = n0 + lane;
+  const int CPB = a.CP * 4;
+
+  unsigned char* wbase = smem + (size_t)wave * a.wave_lds;
+  GroupRec* s_rec = reinterpret_cast<GroupRec*>(wbase);  // [V][64]
+  float2* s_den = reinterpret_cast<float2*>(wbase + (size_t)a.V * kWaveVox * sizeof(GroupRec));
+  constexpr int TSTR = kWaveVox + 1;
+  float* s_out = reinterpret_cast<float*>(s_den + kWaveVox);  // [4L][TSTR]
+
+  auto frame_of = [&](int b) -> int {
+    return (MODE == MODE_WINDOW && a.win_frame != nullptr) ? uniform_load(a.win_frame, b) : b;
+  };
+  auto dead_item = [&](int b) -> bool {
+    return (a.live != nullptr && uniform_load_u8(a.live, b) == 0) ||
+           (unsigned)frame_of(b) >= (unsigned)a.F;
+  };
+
+  // the group's calibration is the one of its first item
+  const int frame0 = frame_of(first);
+  const bool cam_ok = (unsigned)frame0 < (unsigned)a.F;
+
+  float x = 0.f, y = 0.f, z = 0.f;
+  const bool have = cam_ok && n < a.N && voxel_world<MODE>(a, first, n, &x, &y, &z);
+  asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+
+  // ---- project: every view once, records to LDS
+  int cnt = 0;
+  unsigned mbits = 0;
+  unsigned amask = 0;  // slots some lane of the wave needs
+  if (cam_ok) {
+#pragma unroll 1
+    for (int slot = 0; slot < a.V; slot++) {
+      const int view = slot_view(a, slot);
+      const TempoCam cam = load_cam(a.cam, frame0 * a.V + view);
+      TempoPix p;
+      p.px = p.py = 0.f;
+      p.inside = 0;
+      bool need = false;
+      if (have) {
+        p = tempo_world_to_pixel(&cam, x, y, z, UNF);
+        need = MODE != MODE_ROOT || p.inside || p.px != p.px || p.py != p.py;
+      }
+      cnt += p.inside;
+      mbits |= (unsigned)p.inside << view;
+      if (__builtin_amdgcn_ballot_w64(need) != 0) {
+        float gx, gy;
+        tempo_pixel_to_grid(&cam, p.px, p.py, &a.geom, UNF, &gx, &gy);
+        float fw, fn;
+        int x0, y0;
+        tempo_bilinear_frac(gx, gy, a.W, a.H, &x0, &y0, &fw, &fn);
+        GroupRec r;
+        r.base = (unsigned)((y0 * a.W + x0) * CPB);
+        r.flags = ((need && (unsigned)x0 < (unsigned)a.W) ? 1u : 0u) |
+                  ((need && (unsigned)(x0 + 1) < (unsigned)a.W) ? 2u : 0u);
+        r.w = fw;
+        r.n = fn;
+        s_rec[slot * kWaveVox + lane] = r;
+        amask |= 1u << slot;
+      }
+    }
+  }
+  amask = __builtin_amdgcn_readfirstlane(amask);
+  {
+    const float den = (MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f;
+    s_den[lane] = make_float2(den, 1.0f / den);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- gather layout: L lanes per voxel, VPS voxels per sub-step
+  const bool lane_on = lane < VPS * L;
+  const int vq = lane / L;
+  const int cq = lane - vq * L;
+  const unsigned lo = (unsigned)cq * 16u;
+  const unsigned rowb = (unsigned)(a.W * CPB);
+  float2 dr[NSUB];
+  int rdv[NSUB];
+#pragma unroll
+  for (int s = 0; s < NSUB; s++) {
+    const int vsl = s * VPS + vq;
+    rdv[s] = (lane_on && vsl < kWaveVox) ? vsl : 0;
+    dr[s] = s_den[rdv[s]];
+  }
+
+  u32x4 tex[2][G][4];
+  auto make_rsrc = [&](int b, int view, bool real) -> __amdgpu_buffer_rsrc_t {
+    // a dead item's maps are never read: zero records
+    const bool dd = !real || dead_item(b) || !cam_ok;
+    const int fr = dd ? 0 : frame_of(b);
+    const unsigned long long vb = (unsigned long long)(uintptr_t)(
+        reinterpret_cast<const char*>(a.hm + (long long)fr * a.frame_stride) +
+        (long long)view * a.view_bytes);
+    const unsigned vb_lo = __builtin_amdgcn_readfirstlane((unsigned)vb);
+    const unsigned vb_hi = __builtin_amdgcn_readfirstlane((unsigned)(vb >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>((uintptr_t)(((unsigned long long)vb_hi << 32) | vb_lo)), 0,
+        __builtin_amdgcn_readfirstlane(dd ? 0 : (int)a.view_bytes), 0x00020000);
+  };
+  // half h of the view in `slot` -> tex[h].  Always issued (an unconditional
+  // instruction stream keeps the wait counts exact); `real` = false reads a
+  // zero-sized buffer: no memory traffic
+  auto fetch = [&](auto hc, int b, int slot, bool real) {
+    constexpr int h = decltype(hc)::value;
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(b, slot_view(a, slot), real);
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const int s = h * G + g;
+      if (s < NSUB) {
+        const GroupRec r = s_rec[slot * kWaveVox + rdv[s]];
+        const unsigned o0 = (r.flags & 1u) ? r.base : kInvalid;
+        const unsigned o1 = (r.flags & 2u) ? r.base + CPB : kInvalid;
+        const unsigned o2 = (r.flags & 1u) ? r.base + rowb : kInvalid;
+        const unsigned o3 = (r.flags & 2u) ? r.base + rowb + CPB : kInvalid;
+        tex[h][g][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, o0 + lo, 0, 0);
+        tex[h][g][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, o1 + lo, 0, 0);
+        tex[h][g][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, o2 + lo, 0, 0);
+        tex[h][g][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, o3 + lo, 0, 0);
+      }
+    }
+  };
+  f32x2 acc01[NSUB], acc23[NSUB];
+  auto mix = [&](auto hc, int slot) {
+    constexpr int h = decltype(hc)::value;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const int s = h * G + g;
+      if (s < NSUB) {
+        const GroupRec r = s_rec[slot * kWaveVox + rdv[s]];
+        // the weights of tempo_bilinear_tap, from the stored fractions
+        const float e = 1.0f - r.w, sth = 1.0f - r.n;
+        const f32x2 nw = tempo_splat(sth * e), ne = tempo_splat(sth * r.w);
+        const f32x2 sw = tempo_splat(r.n * e), se = tempo_splat(r.n * r.w);
+        const f32x2 a01 = {__uint_as_float(tex[h][g][0][0]), __uint_as_float(tex[h][g][0][1])};
+        const f32x2 a23 = {__uint_as_float(tex[h][g][0][2]), __uint_as_float(tex[h][g][0][3])};
+        const f32x2 b01 = {__uint_as_float(tex[h][g][1][0]), __uint_as_float(tex[h][g][1][1])};
+        const f32x2 b23 = {__uint_as_float(tex[h][g][1][2]), __uint_as_float(tex[h][g][1][3])};
+        const f32x2 c01 = {__uint_as_float(tex[h][g][2][0]), __uint_as_float(tex[h][g][2][1])};
+        const f32x2 c23 = {__uint_as_float(tex[h][g][2][2]), __uint_as_float(tex[h][g][2][3])};
+        const f32x2 d01 = {__uint_as_float(tex[h][g][3][0]), __uint_as_float(tex[h][g][3][1])};
+        const f32x2 d23 = {__uint_as_float(tex[h][g][3][2]), __uint_as_float(tex[h][g][3][3])};
+        f32x2 v01 = a01 * nw, v23 = a23 * nw;
+        v01 = __builtin_elementwise_fma(b01, ne, v01);
+        v23 = __builtin_elementwise_fma(b23, ne, v23);
+        v01 = __builtin_elementwise_fma(c01, sw, v01);
+        v23 = __builtin_elementwise_fma(c23, sw, v23);
+        v01 = __builtin_elementwise_fma(d01, se, v01);
+        v23 = __builtin_elementwise_fma(d23, se, v23);
+        acc01[s] = acc01[s] + v01;
+        acc23[s] = acc23[s] + v23;
+      }
+    }
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+
+  const int slot0 = amask ? __builtin_ctz(amask) : 0;
+  fetch(H0{}, first, slot0, amask != 0);
+#pragma unroll 1
+  for (int fi = 0; fi < nfr; fi++) {
+    const int b = first + fi;
+    const bool dead = !cam_ok || dead_item(b);
+#pragma unroll
+    for (int s = 0; s < NSUB; s++) {
+      acc01[s] = tempo_splat(0.f);
+      acc23[s] = tempo_splat(0.f);
+    }
+    unsigned mm = amask;
+#pragma unroll 1
+    while (mm) {
+      const int slot = __builtin_ctz(mm);
+      mm &= mm - 1;
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(H1{}, b, slot, true);
+      __builtin_amdgcn_sched_barrier(0);
+      mix(H0{}, slot);
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        // the next half view: of this item, or the first of the next item
+        const bool more = mm != 0, last = !more && fi + 1 >= nfr;
+        fetch(H0{}, (more || last) ? b : b + 1, more ? __builtin_ctz(mm) : slot0, !last);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mix(H1{}, slot);
+    }
+
+    // ---- normalise, clamp, transpose, store (as unproject_kernel's phase C)
+    bool odd = false;
+#pragma unroll
+    for (int s = 0; s < NSUB; s++) {
+      acc01[s] = tempo_div_const2(acc01[s], tempo_splat(dr[s].x), tempo_splat(dr[s].y));
+      acc23[s] = tempo_div_const2(acc23[s], tempo_splat(dr[s].x), tempo_splat(dr[s].y));
+      const f32x2 t = acc01[s] + acc23[s];
+      const float u = t.x + t.y;
+      odd |= u != u;
+    }
+    const bool slow = __builtin_amdgcn_ballot_w64(odd) != 0;
+#pragma unroll
+    for (int s = 0; s < NSUB; s++) {
+      const int vsl = s * VPS + vq;
+      if (lane_on && vsl < kWaveVox) {
+        float* o = s_out + (4 * cq) * TSTR + vsl;
+        if (!slow) {
+          o[0 * TSTR] = __builtin_amdgcn_fmed3f(acc01[s].x, 0.0f, 1.0f);
+          o[1 * TSTR] = __builtin_amdgcn_fmed3f(acc01[s].y, 0.0f, 1.0f);
+          o[2 * TSTR] = __builtin_amdgcn_fmed3f(acc23[s].x, 0.0f, 1.0f);
+          o[3 * TSTR] = __builtin_amdgcn_fmed3f(acc23[s].y, 0.0f, 1.0f);
+        } else {
+          o[0 * TSTR] = tempo_nan_clamp(acc01[s].x, 0.0f, 1.0f);
+          o[1 * TSTR] = tempo_nan_clamp(acc01[s].y, 0.0f, 1.0f);
+          o[2 * TSTR] = tempo_nan_clamp(acc23[s].x, 0.0f, 1.0f);
+          o[3 * TSTR] = tempo_nan_clamp(acc23[s].y, 0.0f, 1.0f);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (n < a.N) {
+      float* dst = a.cubes + (long long)b * a.C * a.N + n;
+      if (dead) {
+        for (int ch = 0; ch < a.C; ch++) dst[(long long)ch * a.N] = 0.0f;
+      } else {
+        for (int ch = 0; ch < a.C; ch++) dst[(long long)ch * a.N] = s_out[ch * TSTR + lane];
+      }
+      if (MODE == MODE_ROOT && a.grids != nullptr) {
+        float* gp = a.grids + ((long long)b * a.N + n) * 3;
+        gp[0] = dead ? 0.0f : x;
+        gp[1] = dead ? 0.0f : y;
+        gp[2] = dead ? 0.0f : z;
+      }
+      if (MODE == MODE_ROOT && a.mask != nullptr) {
+        char* m = (char*)a.mask + ((long long)b * a.N + n) * a.mask_bytes;
+        const unsigned mb = dead ? 0u : mbits;
+        if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mb;
+        else if (a.mask_bytes == 2) *(uint16_t*)m = (uint16_t)mb;
+        else *(uint32_t*)m = mb;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------ repack
 struct RepackArgs {
   const float* views[TEMPO_MAX_VIEWS];
@@ -562,6 +884,18 @@ int launch_one(const UnprojArgs& a, hipStream_t stream) {
   const int waves = kThreads / 64;
   k.tile_vox = waves * kWaveVox;
   k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
+  // grouped launch when the records of all views fit the default LDS limit;
+  // otherwise the group table is only a hint and every item projects for itself
+  if (a.groups != nullptr && waves * group_wave_lds(a.V, L) <= 65536) {
+    const long long gtotal = (long long)a.NG * k.tiles;
+    if (gtotal > 0x7fffffffLL / 8) return TEMPO_E_DIM;
+    k.total = (int)gtotal;
+    k.chunk = (k.total + 7) / 8;
+    k.wave_lds = group_wave_lds(a.V, L);
+    hipLaunchKernelGGL((unproject_group_kernel<MODE, L, UNF>), dim3(8 * k.chunk),
+                       dim3(kThreads), (size_t)waves * k.wave_lds, stream, k);
+    return (int)hipGetLastError();
+  }
   const long long total = (long long)a.NB * k.tiles;
   if (total > 0x7fffffffLL / 8) return TEMPO_E_DIM;
   k.total = (int)total;
@@ -665,7 +999,22 @@ int tempo_unproject_root(const float* hm, const float* cam, const float* ax_x,
                          int mask_bytes, int B, int V, int C, int CP, int H, int W, int X,
                          int Y, int Z, float hm_w, float hm_h, float img_w, float img_h,
                          int mm_unfused, void* stream) {
+  return tempo_unproject_root_grouped(hm, cam, ax_x, ax_y, ax_z, ax_batched, live, cubes,
+                                      grids, mask, mask_bytes, B, V, C, CP, H, W, X, Y, Z,
+                                      hm_w, hm_h, img_w, img_h, mm_unfused, nullptr, 0,
+                                      stream);
+}
+
+int tempo_unproject_root_grouped(const float* hm, const float* cam, const float* ax_x,
+                                 const float* ax_y, const float* ax_z, int ax_batched,
+                                 const uint8_t* live, float* cubes, float* grids,
+                                 void* mask, int mask_bytes, int B, int V, int C, int CP,
+                                 int H, int W, int X, int Y, int Z, float hm_w, float hm_h,
+                                 float img_w, float img_h, int mm_unfused,
+                                 const int32_t* groups, int num_groups, void* stream) {
   if (!hm || !cam || !ax_x || !ax_y || !ax_z || !cubes) return TEMPO_E_NULL;
+  if ((groups == nullptr) != (num_groups == 0) || num_groups < 0 || num_groups > B)
+    return TEMPO_E_ARG;
   const int rc = check_common(V, C, CP, H, W);
   if (rc != TEMPO_OK) return rc;
   if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0) return TEMPO_E_DIM;
@@ -688,6 +1037,7 @@ int tempo_unproject_root(const float* hm, const float* cam, const float* ax_x,
   a.NB = B; a.F = B; a.V = V; a.C = C; a.CP = CP; a.H = H; a.W = W;
   a.dim[0] = X; a.dim[1] = Y; a.dim[2] = Z; a.N = (int)N;
   a.geom = tempo_make_geom(hm_w, hm_h, img_w, img_h);
+  a.groups = groups; a.NG = num_groups;
   return launch_mode<MODE_ROOT>(a, mm_unfused, (hipStream_t)stream);
 }
 
@@ -698,8 +1048,25 @@ int tempo_unproject_window(const float* hm, const float* cam, const int32_t* win
                            int CP, int H, int W, int FX, int FY, int FZ, int VX, int VY,
                            int VZ, float hm_w, float hm_h, float img_w, float img_h,
                            int mm_unfused, void* stream) {
+  return tempo_unproject_window_grouped(hm, cam, win_frame, fx, fy, fz, tl, start, end, live,
+                                        cubes, NW, F, V, C, CP, H, W, FX, FY, FZ, VX, VY, VZ,
+                                        hm_w, hm_h, img_w, img_h, mm_unfused, nullptr, 0,
+                                        stream);
+}
+
+int tempo_unproject_window_grouped(const float* hm, const float* cam,
+                                   const int32_t* win_frame, const float* fx,
+                                   const float* fy, const float* fz, const int32_t* tl,
+                                   const int32_t* start, const int32_t* end,
+                                   const uint8_t* live, float* cubes, int NW, int F, int V,
+                                   int C, int CP, int H, int W, int FX, int FY, int FZ,
+                                   int VX, int VY, int VZ, float hm_w, float hm_h,
+                                   float img_w, float img_h, int mm_unfused,
+                                   const int32_t* groups, int num_groups, void* stream) {
   if (!hm || !cam || !fx || !fy || !fz || !tl || !start || !end || !cubes)
     return TEMPO_E_NULL;
+  if ((groups == nullptr) != (num_groups == 0) || num_groups < 0 || num_groups > NW)
+    return TEMPO_E_ARG;
   const int rc = check_common(V, C, CP, H, W);
   if (rc != TEMPO_OK) return rc;
   if (NW <= 0 || F <= 0 || FX <= 0 || FY <= 0 || FZ <= 0 || VX <= 0 || VY <= 0 || VZ <= 0)
@@ -718,6 +1085,7 @@ int tempo_unproject_window(const float* hm, const float* cam, const int32_t* win
   a.dim[0] = VX; a.dim[1] = VY; a.dim[2] = VZ; a.N = (int)N;
   a.fdim[0] = FX; a.fdim[1] = FY; a.fdim[2] = FZ;
   a.geom = tempo_make_geom(hm_w, hm_h, img_w, img_h);
+  a.groups = groups; a.NG = num_groups;
   return launch_mode<MODE_WINDOW>(a, mm_unfused, (hipStream_t)stream);
 }
 

@@ -290,6 +290,19 @@ TEMPO_HD TempoTap tempo_bilinear_tap(float gx, float gy, int W, int H) {
   return t;
 }
 
+// The same footprint as its top-left texel and the two fractions; the weights
+// are then (1-n)(1-w), (1-n)w, n(1-w), nw exactly as above.
+TEMPO_HD void tempo_bilinear_frac(float gx, float gy, int W, int H, int* x0, int* y0,
+                                  float* w, float* n) {
+  const float ix = tempo_unnormalize(gx, (float)W);
+  const float iy = tempo_unnormalize(gy, (float)H);
+  const float fx = floorf(ix), fy = floorf(iy);
+  *w = ix - fx;
+  *n = iy - fy;
+  *x0 = (ix == ix) ? (int)fx : 0;
+  *y0 = (iy == iy) ? (int)fy : 0;
+}
+
 // sample = fma(se_val, se, fma(sw_val, sw, fma(ne_val, ne, nw_val * nw)))
 // (the contraction torch's CPU grid_sample is built with); a texel outside the
 // map reads as 0 (padding_mode='zeros')

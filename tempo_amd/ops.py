@@ -67,12 +67,54 @@ def repack_nhwc(feature_maps, c_begin=0, channels=None, out=None):
     return out
 
 
+GROUP_MAX_ITEMS = 8  # items per work item of a grouped launch (amortisation vs parallelism)
+
+
+def share_groups(keys, max_items=None):
+    """Group table for the ``*_grouped`` entry points: runs of consecutive items
+    with equal ``keys[i]`` (any hashable: the bytes of the item's camera records,
+    its grid centre, its window geometry ...), cut into pieces of at most
+    ``max_items``.  Returns a CPU int32 ``[NG,2]`` tensor of (first, count), or
+    None when nothing is shared."""
+    max_items = GROUP_MAX_ITEMS if max_items is None else int(max_items)
+    rows, i, n = [], 0, len(keys)
+    while i < n:
+        j = i + 1
+        while j < n and j - i < max_items and keys[j] == keys[i]:
+            j += 1
+        rows.append((i, j - i))
+        i = j
+    if len(rows) == n:
+        return None
+    return torch.tensor(rows, dtype=torch.int32)
+
+
+def camera_keys(cam_cpu, extra=None):
+    """One hashable key per item from its packed camera records (bit-exact
+    comparison) and an optional per-item ``extra`` (list of hashables)."""
+    arr = cam_cpu.contiguous().numpy()
+    return [(arr[b].tobytes(), None if extra is None else extra[b])
+            for b in range(arr.shape[0])]
+
+
+def _groups_arg(groups, n_items, dev):
+    if groups is None:
+        return None, 0
+    _need(groups, torch.int32, 'groups', dev)
+    if groups.dim() != 2 or groups.shape[1] != 2 or groups.shape[0] > n_items:
+        raise ValueError('groups must be int32 [NG,2] with NG <= number of items')
+    return groups, int(groups.shape[0])
+
+
 def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
-                   want_grids=False, want_mask=False, out=None, mm_mode='auto'):
+                   want_grids=False, want_mask=False, out=None, mm_mode='auto',
+                   groups=None):
     """Root-grid unprojection on a repacked heatmap tensor.
 
     hm ``[B,V,H,W,CP]``; cam ``[B,V,32]``; axes = (ax_x, ax_y, ax_z), each
-    ``[X]`` (shared) or ``[B,X]`` (per batch item).  Returns
+    ``[X]`` (shared) or ``[B,X]`` (per batch item).  ``groups``: device int32
+    ``[NG,2]`` from :func:`share_groups` (items of a group share camera records
+    and axes; the projection then runs once per group).  Returns
     ``(cubes [B,C,X,Y,Z], grids [B,N,3] | None, mask [B,N] | None)``.
     """
     lib = _lib.load()
@@ -106,23 +148,26 @@ def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
         mask_bytes = 1 if V <= 8 else (2 if V <= 16 else 4)
         mdt = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[mask_bytes]
         mask = torch.empty(B, N, dtype=mdt, device=dev)
+    groups, ng = _groups_arg(groups, B, dev)
     with torch.cuda.device(dev):
-        rc = lib.tempo_unproject_root(
+        rc = lib.tempo_unproject_root_grouped(
             _ptr(hm), _ptr(cam), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), int(batched),
             _ptr(live), _ptr(out), _ptr(grids), _ptr(mask), mask_bytes, B, V, C, CP, H, W,
             X, Y, Z, float(heatmap_size[0]), float(heatmap_size[1]),
             float(image_size[0]), float(image_size[1]), numerics.abi_flag(mm_mode),
-            _stream_ptr(dev))
-    _lib.check(rc, 'tempo_unproject_root')
+            _ptr(groups), ng, _stream_ptr(dev))
+    _lib.check(rc, 'tempo_unproject_root_grouped')
     return out, grids, mask
 
 
 def unproject_window(hm, cam, fine_axes, tl, start, end, sub_cube, channels,
                      heatmap_size, image_size, win_frame=None, live=None, out=None,
-                     mm_mode='auto'):
+                     mm_mode='auto', groups=None):
     """Per-person window unprojection.  hm ``[F,V,H,W,CP]``, cam ``[F,V,32]``,
     tl/start/end int32 ``[NW,3]``, win_frame int32 ``[NW]`` or None (NW == F).
-    Returns cubes ``[NW,C,VX,VY,VZ]``."""
+    ``groups``: device int32 ``[NG,2]``, runs of consecutive windows with equal
+    tl/start/end whose frames have equal camera records (the T timesteps of one
+    proposal).  Returns cubes ``[NW,C,VX,VY,VZ]``."""
     lib = _lib.load()
     dev = hm.device
     _need(hm, torch.float32, 'hm')
@@ -154,14 +199,16 @@ def unproject_window(hm, cam, fine_axes, tl, start, end, sub_cube, channels,
         _need(out, torch.float32, 'out', dev)
         if out.numel() != NW * C * VX * VY * VZ:
             raise ValueError('out has the wrong size')
+    groups, ng = _groups_arg(groups, NW, dev)
     with torch.cuda.device(dev):
-        rc = lib.tempo_unproject_window(
+        rc = lib.tempo_unproject_window_grouped(
             _ptr(hm), _ptr(cam), _ptr(win_frame), _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]),
             _ptr(tl), _ptr(start), _ptr(end), _ptr(live), _ptr(out), NW, F_, V, C, CP, H,
             W, int(fa[0].numel()), int(fa[1].numel()), int(fa[2].numel()), VX, VY, VZ,
             float(heatmap_size[0]), float(heatmap_size[1]), float(image_size[0]),
-            float(image_size[1]), numerics.abi_flag(mm_mode), _stream_ptr(dev))
-    _lib.check(rc, 'tempo_unproject_window')
+            float(image_size[1]), numerics.abi_flag(mm_mode), _ptr(groups), ng,
+            _stream_ptr(dev))
+    _lib.check(rc, 'tempo_unproject_window_grouped')
     return out
 
 

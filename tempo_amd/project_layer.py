@@ -72,6 +72,9 @@ class ProjectLayer(nn.Module):
         self.last_mask = None  # valid-view bitmap of the last call when keep_mask
         self.keep_mask = False
         self.materialize_grids = True  # the reference's 2nd return; callers drop it
+        # batch items with bit-identical camera records and grid centre (frames of
+        # one recording) share one projection per voxel; results do not change
+        self.share_projection = True
 
     def compute_grid(self, box_size, box_center, num_bins, device=None):
         """``project_layer.py:43-63``: ``[N,3]`` voxel centres, z fastest."""
@@ -108,6 +111,21 @@ class ProjectLayer(nn.Module):
         flags = [1 if float(grid_center[b][3]) >= 0 else 0 for b in range(B)]
         return None if all(flags) else torch.tensor(flags, dtype=torch.uint8, device=device)
 
+    def _share_groups(self, cam_host, grid_center, B):
+        """Runs of consecutive batch items whose packed camera records and grid
+        centre are bit-identical (host-side comparison, no device sync)."""
+        if not self.share_projection or B < 2:
+            return None
+        if len(grid_center) == 1:
+            extra = None
+        elif isinstance(grid_center, torch.Tensor):
+            if grid_center.is_cuda:
+                return None  # comparing centres would need a device sync
+            extra = [tuple(float(v) for v in grid_center[b, :3]) for b in range(B)]
+        else:
+            extra = [tuple(float(grid_center[b][i]) for i in range(3)) for b in range(B)]
+        return ops.share_groups(ops.camera_keys(cam_host, extra))
+
     def get_voxel(self, feature_maps, grid_size, grid_center, cube_size, centers,
                   scales, cameras, zslab=None):
         """``zslab=(z0, z1)`` (extension, used by ``tempo_amd.parallel``): compute
@@ -122,8 +140,11 @@ class ProjectLayer(nn.Module):
                 raise ValueError(f'zslab {zslab} outside [0, {cube_size[2]}]')
             axes[2] = axes[2][..., z0:z1].contiguous()
             cube_size = [cube_size[0], cube_size[1], z1 - z0]
-        cam = pack_cameras(centers, scales, cameras, self.image_size,
-                           self.mm_mode).to(device)
+        cam_host = pack_cameras(centers, scales, cameras, self.image_size, self.mm_mode)
+        cam = cam_host.to(device)
+        groups = self._share_groups(cam_host, grid_center, B)
+        if groups is not None:
+            groups = groups.to(device)
         cubes = torch.empty(B, C, *cube_size, dtype=torch.float32, device=device)
         grids = mask = None
         for c0, cs in _Slices(C).items:
@@ -133,7 +154,7 @@ class ProjectLayer(nn.Module):
                 hm, cam, axes, cs, self.heatmap_size, self.image_size, live=live,
                 want_grids=first and self.materialize_grids,
                 want_mask=first and self.keep_mask,
-                out=cubes if cs == C else None, mm_mode=self.mm_mode)
+                out=cubes if cs == C else None, mm_mode=self.mm_mode, groups=groups)
             if cs != C:
                 cubes[:, c0:c0 + cs] = out
             if first:

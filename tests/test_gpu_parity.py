@@ -37,7 +37,7 @@ def _report(name, got, ref):
 def test_library_loaded_from_tree():
     from tempo_amd import _lib
     lib = _lib.load()
-    assert lib.tempo_version() == 1
+    assert lib.tempo_version() == _lib.ABI_VERSION
     assert os.path.dirname(_lib.LIB_PATH).endswith(os.path.join('tempo_amd', 'lib'))
 
 
@@ -141,3 +141,92 @@ def test_repack_matches_permute(gpu_device):
         ref = torch.zeros(B, V, H, W, cp, device=gpu_device)
         ref[..., :C] = torch.stack(fms, 1).permute(0, 1, 3, 4, 2)
         assert torch.equal(out, ref)
+
+
+def _mixed_calibration_case(seed=31, B=7, cube=(14, 10, 9)):
+    """B frames from three recordings: calibrations A A A B B A C, distinct noise maps."""
+    from tempo_amd import synthetic as S
+    cfg = S.PANOPTIC
+    rings = [S.ring_cameras(5, seed=seed + k, target=cfg['space_center']) for k in range(3)]
+    which = [0, 0, 0, 1, 1, 0, 2][:B]
+    metas = [S.frame_meta(rings[k], 1, cfg['raw_size'], cfg['image_size']) for k in which]
+    centers = [m[0][0] for m in metas]
+    scales = [m[1][0] for m in metas]
+    cameras = [m[2][0] for m in metas]
+    w, h = cfg['heatmap_size']
+    fms = S.make_heatmaps(B, 5, cfg['num_joints'], h, w, kind='noise', seed=seed)
+    return cfg, fms, centers, scales, cameras, list(cube)
+
+
+def test_root_shared_projection_equals_per_item(gpu_device):
+    """Grouped launch (one projection per run of frames with one calibration) vs the
+    per-item launch: bit-identical volume, grids and mask; and vs the oracle."""
+    import tempo_amd
+    cfg, fms, centers, scales, cameras, cube = _mixed_calibration_case()
+    # len-4 centres: item 1 (inside the first run) is skipped by the rule of :81
+    gc = [list(cfg['space_center']) + [(-1.0 if b == 1 else float(b))] for b in range(len(centers))]
+    ref_layer = O.ProjectLayer(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    ref_cubes, ref_grids = ref_layer(fms, cfg['space_size'], gc, cube, centers, scales, cameras)
+    dfms = [t.to(gpu_device) for t in fms]
+    outs = []
+    for share in (True, False):
+        layer = tempo_amd.ProjectLayer(cfg['image_size'], cfg['heatmap_size'], 'mean')
+        layer.keep_mask = True
+        layer.share_projection = share
+        with torch.no_grad():
+            cubes, grids = layer(dfms, cfg['space_size'], gc, cube, centers, scales, cameras)
+        outs.append((cubes.cpu(), grids.cpu(), layer.last_mask.cpu()))
+    canon = lambda t: torch.nan_to_num(t, nan=-7777.0).view(torch.int32)
+    assert torch.equal(canon(outs[0][0]), canon(outs[1][0])), 'volume: grouped vs per-item'
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    assert float((outs[0][0][1]).abs().max()) == 0.0  # the skipped item stays zero
+    err = _report('root_shared', outs[0][0], ref_cubes)
+    assert err <= TOL
+    assert torch.equal(outs[0][1], ref_grids)
+    assert torch.equal(outs[0][2].to(torch.int32), _bits(ref_layer.last_bounding))
+
+
+@pytest.mark.parametrize('cfgname', ['panoptic', 'h36m'])
+def test_window_shared_projection_equals_per_item(cfgname, gpu_device):
+    """T timesteps of one proposal (same window, same calibration, different maps):
+    grouped launch vs per-item launch, bit-identical; both vs the oracle run per timestep."""
+    import tempo_amd
+    from tempo_amd import ops, synthetic as S
+    from tempo_amd.camera import pack_cameras
+    cfg = S.PANOPTIC if cfgname == 'panoptic' else dict(S.H36M, heatmap_size=[96, 96],
+                                                        image_size=[96, 96])
+    cams = (S.ring_cameras(5, seed=41, target=cfg['space_center']) if cfgname == 'panoptic'
+            else S.h36m_cameras())
+    T, P = 3, 3  # timesteps, proposals; windows ordered (proposal, timestep)
+    V, J = len(cams), cfg['num_joints']
+    w, h = cfg['heatmap_size']
+    space, sub, sub_cube = [2400, 2400, 1800], [1200, 1200, 900], [12, 12, 12]
+    fms = S.make_heatmaps(T, V, J, h, w, kind='noise', seed=42)  # frame = timestep
+    centers, scales, cameras = S.frame_meta(cams, T, cfg['raw_size'], cfg['image_size'])
+    props = S.make_proposals(P, cfg['space_center'], space, seed=43, invalid_every=3, margin=0.0)
+    layer = tempo_amd.ProjectLayerWithMask(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    layer.set_space_size(cfg['space_center'], space, sub, sub_cube, gpu_device)
+    tl, _, st, en = layer.window_geometry(props.to(gpu_device))
+    layer._ensure_grids(gpu_device)
+    rep = lambda t: t.to(torch.int32).repeat_interleave(T, 0).contiguous()
+    win_frame = torch.arange(T, dtype=torch.int32, device=gpu_device).repeat(P).contiguous()
+    live = (props[:, 3] >= 0).to(torch.uint8).repeat_interleave(T).to(gpu_device)
+    cam = pack_cameras(centers, scales, cameras, cfg['image_size']).to(gpu_device)
+    hm = ops.repack_nhwc([t.to(gpu_device) for t in fms])
+    groups = torch.tensor([[p * T, T] for p in range(P)], dtype=torch.int32, device=gpu_device)
+    kw = dict(win_frame=win_frame, live=live)
+    a = ops.unproject_window(hm, cam, layer._fine_axes, rep(tl), rep(st), rep(en), sub_cube, J,
+                             cfg['heatmap_size'], cfg['image_size'], groups=groups, **kw)
+    b = ops.unproject_window(hm, cam, layer._fine_axes, rep(tl), rep(st), rep(en), sub_cube, J,
+                             cfg['heatmap_size'], cfg['image_size'], **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b), 'window volume: grouped vs per-item'
+    ref_layer = O.ProjectLayerWithMask(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    for t in range(T):
+        # the reference's call for timestep t: every proposal against frame t
+        f_t = [fm[t:t + 1].expand(P, -1, -1, -1).contiguous() for fm in fms]
+        c3 = lambda x: [x[t]] * P
+        ref, _ = ref_layer(f_t, props, cfg['space_center'], space, sub, sub_cube,
+                           c3(centers), c3(scales), c3(cameras))
+        got = a.view(P, T, *a.shape[1:])[:, t].cpu()
+        assert float((got - ref).abs().max()) <= TOL

@@ -127,3 +127,11 @@ def test_root_axes_and_skip_flags():
     axes, _ = layer._axes(2000, gc, 4, 3, 'cpu')
     assert axes[0].shape == (3, 4)
     assert torch.equal(axes[1][1], torch.linspace(-1000, 1000, 4) + 6.0)
+
+
+def test_share_groups_table():
+    from tempo_amd import ops
+    t = ops.share_groups(['a', 'a', 'a', 'b', 'b', 'a', 'c'])
+    assert t.tolist() == [[0, 3], [3, 2], [5, 1], [6, 1]]
+    assert ops.share_groups(['a', 'b', 'c']) is None
+    assert ops.share_groups(['a'] * 5, max_items=2).tolist() == [[0, 2], [2, 2], [4, 1]]
