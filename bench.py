@@ -35,24 +35,32 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--workload', default='root', choices=['root', 'window'])
+    ap.add_argument('--workload', default='root', choices=['root', 'window', 'window_h36m'])
+    ap.add_argument('--timesteps', type=int, default=None,
+                    help='window workloads: frames per sequence; the T windows of one proposal '
+                         'share geometry and calibration (default 1; window_h36m: 4)')
     ap.add_argument('--batch', type=int, default=32, help='frames per GPU')
     ap.add_argument('--proposals', type=int, default=10, help='window workload only')
     ap.add_argument('--calibrations', type=int, default=1,
                     help='distinct camera calibrations in the batch (recordings the frames '
                          'come from); frames of one calibration are consecutive')
-    ap.add_argument('--no-share', action='store_true',
-                    help='project every frame for itself even when calibrations repeat')
+    ap.add_argument('--share', action='store_true',
+                    help='grouped launch: one projection per run of frames / timesteps with '
+                         'one calibration (measured slower than per-item launches on MI355X)')
     ap.add_argument('--group-max', type=int, default=None, help='frames per shared projection')
+    ap.add_argument('--planes', default='off', choices=['off', 'with', 'only'],
+                    help='window workloads: fused axis-max planes (tempo_pose.py:172-176) '
+                         'next to the volume, or instead of it')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
 
 
-def make_inputs(args, dev, seed):
-    """Synthetic, seeded: U[0,1) heatmaps generated on the device, ring cameras."""
+def make_inputs(args, dev, seed, cfg=None):
+    """Synthetic, seeded: U[0,1) heatmaps generated on the device, ring cameras
+    (Panoptic-like) or the four H36M S1 cameras."""
     from tempo_amd import synthetic as S
     from tempo_amd.camera import pack_cameras
-    cfg = S.PANOPTIC
+    cfg = S.PANOPTIC if cfg is None else cfg
     B, V, J = args.batch, cfg['num_views'], cfg['num_joints']
     w, h = cfg['heatmap_size']
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -60,7 +68,8 @@ def make_inputs(args, dev, seed):
     ncal = max(1, min(args.calibrations, B))
     centers, scales, cameras = [], [], []
     for k in range(ncal):
-        cams = S.ring_cameras(V, seed=seed + 1000 * k, target=cfg['space_center'])
+        cams = (S.h36m_cameras() if cfg is S.H36M else
+                S.ring_cameras(V, seed=seed + 1000 * k, target=cfg['space_center']))
         nb = (B * (k + 1)) // ncal - (B * k) // ncal
         c, s, m = S.frame_meta(cams, nb, cfg['raw_size'], cfg['image_size'])
         centers += c
@@ -81,7 +90,7 @@ class RootWorkload:
         self.B, self.V, self.J = args.batch, cfg['num_views'], cfg['num_joints']
         # frames with bit-identical camera records share one projection per voxel
         self.groups = None
-        if not args.no_share:
+        if args.share:
             g = ops.share_groups(ops.camera_keys(cam_host), args.group_max)
             self.groups = None if g is None else g.to(dev)
         self.axes = [(PL._base_axis(cfg['space_size'][i], cfg['cube_size'][i]) +
@@ -113,50 +122,98 @@ class RootWorkload:
 
 
 class WindowWorkload:
+    """BASELINE configs[2]: 64^3 windows, 10 proposals x 32 frames, Panoptic cam5.
+    With --timesteps T the frames are B/T sequences of T frames and every proposal
+    is unprojected at each of its sequence's T frames (tempo_pose.py:145-156):
+    those T windows share geometry and calibration, hence one projection."""
     name = 'panoptic_cam5_window_64cubed_10prop_b32'
+    cfg_src = 'PANOPTIC'
+    default_T = 1
 
     def __init__(self, args, dev, seed):
         from tempo_amd import ops, project_layer as PL, synthetic as S
         self.ops = ops
-        self.cfg, self.fms, self.cam, _ = make_inputs(args, dev, seed)
+        self.cfg, self.fms, self.cam, _ = make_inputs(args, dev, seed, getattr(S, self.cfg_src))
         cfg = self.cfg
         self.B, self.V, self.J = args.batch, cfg['num_views'], cfg['num_joints']
         P = args.proposals
+        T = self.T = args.timesteps or self.default_T
+        if self.B % T:
+            raise SystemExit('--batch must be a multiple of --timesteps')
         self.NW = self.B * P
         layer = PL.ProjectLayerWithMask(cfg['image_size'], cfg['heatmap_size'], 'mean')
         layer.set_space_size(cfg['space_center'], cfg['space_size'], cfg['sub_space_size'],
                              cfg['sub_cube_size'], dev)
-        props = S.make_proposals(self.NW, cfg['space_center'], cfg['space_size'], seed=seed,
+        # one proposal list per sequence; windows ordered (sequence, proposal, timestep)
+        props = S.make_proposals(self.NW // T, cfg['space_center'], cfg['space_size'], seed=seed,
                                  invalid_every=0, margin=0.15).to(dev)
         props[:, 5:7] = 1.0  # full windows: every voxel is sampled
+        props = props.repeat_interleave(T, 0)
         tl, _, st, en = layer.window_geometry(props)
         layer._ensure_grids(dev)
         self.geo = [t.to(torch.int32).contiguous() for t in (tl, st, en)]
         self.fine = layer._fine_axes
         self.sub = layer._sub_cube
-        self.win_frame = (torch.arange(self.NW, device=dev, dtype=torch.int32) // P).contiguous()
+        i = torch.arange(self.NW, device=dev, dtype=torch.int32)
+        self.win_frame = ((i // (P * T)) * T + i % T).to(torch.int32).contiguous()
+        self.groups = None
+        if T > 1 and args.share:
+            self.groups = torch.tensor([[k * T, T] for k in range(self.NW // T)],
+                                       dtype=torch.int32, device=dev)
         w, h = cfg['heatmap_size']
         cp = ops.padded_channels(self.J)
         self.hm = torch.empty(self.B, self.V, h, w, cp, device=dev)
         self.N = self.sub[0] * self.sub[1] * self.sub[2]
-        self.out = torch.empty(self.NW, self.J, *self.sub, device=dev)
+        self.planes_mode = args.planes
+        self.out = (torch.empty(self.NW, self.J, *self.sub, device=dev)
+                    if args.planes != 'only' else None)
+        sx, sy, sz = self.sub
+        self.planes = [torch.empty(self.NW, self.J, *sh, device=dev)
+                       for sh in ((sx, sy), (sx, sz), (sy, sz))] if args.planes != 'off' else None
         self.samples = self.NW * self.N * self.V
-        self.kernel_bytes = (4 * self.NW * self.J * self.N + 4 * self.B * self.V * self.J * h * w
+        # algorithmic bytes: outputs written once + every heatmap element read once + cameras
+        out_elems = (self.NW * self.J * self.N if args.planes != 'only' else 0) + \
+                    (self.NW * self.J * (sx * sy + sx * sz + sy * sz) if args.planes != 'off' else 0)
+        self.kernel_bytes = (4 * out_elems + 4 * self.B * self.V * self.J * h * w
                              + 128 * self.B * self.V)
-        self.kernel_name = 'unproject_kernel<WINDOW>'
+        self.kernel_name = ('unproject_group_kernel<WINDOW>' if self.groups is not None
+                            else 'unproject_planes_kernel' if args.planes != 'off'
+                            else 'unproject_kernel<WINDOW>')
 
     def repack(self):
         self.ops.repack_nhwc(self.fms, out=self.hm)
 
     def kernel(self):
         tl, st, en = self.geo
+        if self.planes_mode != 'off':
+            self.ops.unproject_window_planes(
+                self.hm, self.cam, self.fine, tl, st, en, self.sub, self.J,
+                self.cfg['heatmap_size'], self.cfg['image_size'], win_frame=self.win_frame,
+                want_cubes=self.planes_mode == 'with', out=self.out, planes_out=self.planes)
+            return
         self.ops.unproject_window(self.hm, self.cam, self.fine, tl, st, en, self.sub, self.J,
                                   self.cfg['heatmap_size'], self.cfg['image_size'],
-                                  win_frame=self.win_frame, out=self.out)
+                                  win_frame=self.win_frame, out=self.out, groups=self.groups)
 
     def step(self):
         self.repack()
         self.kernel()
+
+
+class WindowH36MWorkload(WindowWorkload):
+    """BASELINE configs[3], one GPU's slice: H36M 4 cameras, 17 joints, 384x384 maps,
+    64^3 window, 1 person, T = 4 frames per sequence (run with --batch 128 for the
+    128 windows per GPU of the 8-GPU split)."""
+    name = 'h36m_cam4_window_64cubed_T4'
+    cfg_src = 'H36M'
+    default_T = 4
+
+
+def make_workload(args, dev, seed):
+    if args.workload == 'window_h36m' and args.proposals == 10:
+        args.proposals = 1  # one person per sequence
+    return {'root': RootWorkload, 'window': WindowWorkload,
+            'window_h36m': WindowH36MWorkload}[args.workload](args, dev, seed)
 
 
 def cpu_baseline(args):
@@ -210,6 +267,9 @@ def measured_traffic(args, wl):
     64 B per fabric request; this kernel's texel fetches are 64-byte requests, so it is taken at
     face value (calibration: profiles/r01/fetch_size_calibration.txt)."""
     import csv
+    if (args.workload == 'window_h36m' or (args.timesteps or 1) != 1 or args.calibrations != 1
+            or args.planes != 'off' or args.share):
+        return None, None
     tag = 'root' if args.workload == 'root' else 'window'
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01',
                         tag + '_pmc_summary.csv')
@@ -240,7 +300,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    wl = (RootWorkload if args.workload == 'root' else WindowWorkload)(args, dev, seed=rank)
+    wl = make_workload(args, dev, seed=rank)
 
     def barrier():
         if dist is not None:
@@ -276,6 +336,35 @@ def main():
     k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     r_ms = sum(c.elapsed_time(d) for c, d in rp) / len(rp)
 
+    # fused epilogue: what the reference's caller does instead (tempo_pose.py:172-176) --
+    # the volume kernel followed by torch.max over each axis, on the same inputs
+    unfused = None
+    if rank == 0 and getattr(wl, 'planes_mode', 'off') != 'off':
+        vol = wl.out if wl.out is not None else torch.empty(wl.NW, wl.J, *wl.sub, device=dev)
+        tl, st, en = wl.geo
+
+        def unfused_step():
+            wl.ops.unproject_window(wl.hm, wl.cam, wl.fine, tl, st, en, wl.sub, wl.J,
+                                    wl.cfg['heatmap_size'], wl.cfg['image_size'],
+                                    win_frame=wl.win_frame, out=vol)
+            return vol.max(dim=4)[0], vol.max(dim=3)[0], vol.max(dim=2)[0]
+
+        for _ in range(3):
+            unfused_step()
+        u0, u1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        u0.record()
+        for _ in range(10):
+            ref_planes = unfused_step()
+        u1.record()
+        torch.cuda.synchronize()
+        wl.kernel()
+        torch.cuda.synchronize()
+        same = all(torch.equal(torch.nan_to_num(p, nan=-1.0), torch.nan_to_num(q, nan=-1.0))
+                   for p, q in zip(wl.planes, ref_planes))
+        unfused = {'ms': round(u0.elapsed_time(u1) / 10, 4), 'planes_bit_identical': same,
+                   'what': 'unproject_window (volume) + torch.max over z, y, x'}
+        del vol, ref_planes
+
     if rank == 0:
         traffic, traffic_src = measured_traffic(args, wl)
         ms_step = elapsed / args.steps * 1e3
@@ -291,6 +380,8 @@ def main():
             'config': {'workload': wl.name, 'frames_per_gpu': args.batch,
                        'calibrations_per_batch': max(1, min(args.calibrations, args.batch)),
                        'shared_projection': getattr(wl, 'groups', None) is not None,
+                       'timesteps': getattr(wl, 'T', 1),
+                       'planes': getattr(wl, 'planes_mode', 'off'),
                        'views': wl.V,
                        'joints': wl.J, 'samples_per_step_per_gpu': wl.samples,
                        'partition': f'frames x proposals over {world} rank(s), no collective'},
@@ -303,6 +394,8 @@ def main():
             'repack_ms': round(r_ms, 4),
             'kernel_gsamp_s': round(wl.samples / (k_ms * 1e-3) / 1e9, 3),
         }
+        if unfused is not None:
+            line['unfused_consumer'] = unfused
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(line), flush=True)

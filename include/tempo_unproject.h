@@ -160,6 +160,29 @@ int tempo_unproject_window_grouped(const float* hm, const float* cam,
                                    const int32_t* groups, int num_groups,
                                    void* stream);
 
+/* tempo_unproject_window with the pose regressor's axis-max fused in: the only
+ * consumer of the window volume takes its maximum along z, y and x
+ * (tempo_pose.py:172-176: torch.max(cubes, dim=5 / 4 / 3)).
+ *   cubes    : out fp32 [NW, C, VX, VY, VZ], or NULL to skip the volume
+ *   plane_xy : out fp32 [NW, C, VX, VY] = max over z, or NULL
+ *   plane_xz : out fp32 [NW, C, VX, VZ] = max over y, or NULL
+ *   plane_yz : out fp32 [NW, C, VY, VZ] = max over x, or NULL
+ * Values are bit-identical to torch.max over the volume tempo_unproject_window
+ * writes; a NaN voxel makes its three plane entries NaN (as torch.max does; the
+ * NaN's payload bits are not specified).  The planes are cleared on `stream`
+ * before the launch. */
+int tempo_unproject_window_planes(const float* hm, const float* cam,
+                                  const int32_t* win_frame, const float* fx,
+                                  const float* fy, const float* fz,
+                                  const int32_t* tl, const int32_t* start,
+                                  const int32_t* end, const uint8_t* live,
+                                  float* cubes, float* plane_xy, float* plane_xz,
+                                  float* plane_yz, int NW, int F, int V, int C,
+                                  int CP, int H, int W, int FX, int FY, int FZ,
+                                  int VX, int VY, int VZ, float hm_w, float hm_h,
+                                  float img_w, float img_h, int mm_unfused,
+                                  void* stream);
+
 /* Projection only, for parity checks of the coordinate chain
  * (SimpleCameraTorch.world_to_pixel + project_layer.py:113-126):
  *   pts [N,3] world points, cam [M,32]  ->  pix [M,N,2] source-image pixels,

@@ -30,6 +30,8 @@ SIGNATURES = {
     'tempo_unproject_window_grouped': (_c_int, [_c_void_p] * 11 + [_c_int] * 13 +
                                        [_c_float] * 4 +
                                        [_c_int, _c_void_p, _c_int, _c_void_p]),
+    'tempo_unproject_window_planes': (_c_int, [_c_void_p] * 14 + [_c_int] * 13 +
+                                      [_c_float] * 4 + [_c_int, _c_void_p]),
     'tempo_project_points': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int] +
                              [_c_float] * 4 + [_c_int] + [_c_void_p] * 4),
 }

@@ -34,6 +34,12 @@
 
 namespace {
 
+#ifndef TEMPO_SB_ROOT
+#define TEMPO_SB_ROOT 8
+#endif
+#ifndef TEMPO_SB_WINDOW
+#define TEMPO_SB_WINDOW 1
+#endif
 constexpr int kThreads = 256;
 constexpr int kWaveVox = 64;                // voxels per wave
 // LDS bytes per wave: 2 x 64 records of 32 B while gathering, then the [CP][65]
@@ -76,6 +82,11 @@ struct UnprojArgs {
   int chunk;    // ceil(total / 8): contiguous run of work items per XCD label
   int mask_bytes;
   TempoGeom geom;
+  // axis-max planes (fused epilogue), or nullptr: [NB][C][d0][d1], [NB][C][d0][d2],
+  // [NB][C][d1][d2] as unsigned bit patterns of non-negative floats, zero-initialised
+  unsigned* pl01;
+  unsigned* pl02;
+  unsigned* pl12;
   const int32_t* groups;  // grouped launch: [NG][2] = (first item, count), or nullptr
   int NG;
   int wave_lds;  // grouped launch: LDS bytes per wave
@@ -92,6 +103,10 @@ template <typename T>
 __device__ __forceinline__ T uniform_load(const T* p, long long i) {
   const T TEMPO_AS4* q = (const T TEMPO_AS4*)(uintptr_t)(p + i);
   return *q;
+}
+
+__device__ __forceinline__ int texel_index(int y0, int W, int x0) {
+  return __mul24(y0, W) + x0;
 }
 
 // one byte, wave-uniform: the scalar unit has no byte loads (a byte read would
@@ -114,6 +129,74 @@ __device__ __forceinline__ TempoCam load_cam(const float* cam, int rec) {
 #pragma unroll
   for (int i = 0; i < CAM_FLOATS; i++) d[i] = q[i];
   return c;
+}
+
+// maximum over the wave of non-negative-float bit patterns (0 = identity);
+// the result is valid in lane 63
+__device__ __forceinline__ unsigned wave_umax_to_lane63(unsigned v) {
+  auto step = [&](auto ctrl, auto rmask) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(
+        0, (int)v, decltype(ctrl)::value, decltype(rmask)::value, 0xf, true);
+    v = o > v ? o : v;
+  };
+  using std::integral_constant;
+  step(integral_constant<int, 0x111>{}, integral_constant<int, 0xf>{});  // row_shr:1
+  step(integral_constant<int, 0x112>{}, integral_constant<int, 0xf>{});  // row_shr:2
+  step(integral_constant<int, 0x114>{}, integral_constant<int, 0xf>{});  // row_shr:4
+  step(integral_constant<int, 0x118>{}, integral_constant<int, 0xf>{});  // row_shr:8
+  step(integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});  // row_bcast:15
+  step(integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});  // row_bcast:31
+  return v;
+}
+
+__device__ __forceinline__ void voxel_index(const UnprojArgs& a, int n, int* i0, int* i1,
+                                            int* i2) {
+  unsigned t = __umulhi((unsigned)n, a.magic[0]);
+  unsigned r2 = (unsigned)n - t * (unsigned)a.dim[2];
+  if (r2 >= (unsigned)a.dim[2]) { r2 -= (unsigned)a.dim[2]; t++; }
+  unsigned q0 = __umulhi(t, a.magic[1]);
+  unsigned r1 = t - q0 * (unsigned)a.dim[1];
+  if (r1 >= (unsigned)a.dim[1]) { r1 -= (unsigned)a.dim[1]; q0++; }
+  *i2 = (int)r2;
+  *i1 = (int)r1;
+  *i0 = (int)q0;
+}
+
+// Fused axis-max epilogue: the finished [C][64 voxels] tile of one wave (s_out,
+// lane = voxel) goes into the three max-projection planes the pose regressor
+// builds from the window volume (tempo_pose.py:172-176; center_net.py:230 for
+// the root grid's z-max).  Values are clamped to [0,1] (or NaN), so their bit
+// patterns order like unsigned integers and NaN (larger than 1.0f) wins, as in
+// torch.max.  Along the fastest axis the wave reduces in registers when it
+// holds exactly one column; everything else is a no-return atomic max.
+__device__ __forceinline__ void planes_epilogue(const UnprojArgs& a, int b, int n0, int lane,
+                                                const float* s_out, int tstr) {
+  const int n = n0 + lane;
+  const bool on = n < a.N;
+  int i0 = 0, i1 = 0, i2 = 0;
+  if (on) voxel_index(a, n, &i0, &i1, &i2);
+  const bool column = a.dim[2] == kWaveVox;  // n0 is a multiple of 64: one whole column
+  const long long bc = (long long)b * a.C;
+  for (int ch = 0; ch < a.C; ch++) {
+    const unsigned v = on ? __float_as_uint(s_out[ch * tstr + lane]) : 0u;
+    if (v != 0u) {
+      if (a.pl02 != nullptr)
+        __hip_atomic_fetch_max(a.pl02 + ((bc + ch) * a.dim[0] + i0) * a.dim[2] + i2, v,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.pl12 != nullptr)
+        __hip_atomic_fetch_max(a.pl12 + ((bc + ch) * a.dim[1] + i1) * a.dim[2] + i2, v,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (a.pl01 != nullptr) {
+      unsigned* dst = a.pl01 + ((bc + ch) * a.dim[0] + i0) * a.dim[1] + i1;
+      if (column) {
+        const unsigned m = wave_umax_to_lane63(v);
+        if (lane == 63) *dst = m;
+      } else if (v != 0u) {
+        __hip_atomic_fetch_max(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 template <int MODE>
@@ -151,53 +234,20 @@ __device__ __forceinline__ bool voxel_world(const UnprojArgs& a, int b, int n,
   }
 }
 
+// One wave's 64 voxels [n0, n0 + 64) of batch item / window b, all views: leaves
+// the finished tile (normalised, clamped) in the wave's LDS, [4L channels][65]
+// floats at wbase, lane = voxel; writes the optional grids / mask outputs.
 template <int MODE, int L, int SB, int UNF>
-__global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a) {
+__device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int frame, int n0,
+                                               int lane, unsigned char* wbase) {
   constexpr int VPS = 64 / L;                       // voxels per sub-step of phase B
   constexpr int NSUB = (kWaveVox + VPS - 1) / VPS;  // sub-steps per wave
-  extern __shared__ __align__(16) unsigned char smem[];
-
-  // XCD-aware work order: workgroups b, b+8, b+16.. share an XCD (and its L2);
-  // give each such group one contiguous run of (batch item, tile) pairs so an
-  // XCD's L2 holds the heatmaps of one frame at a time.
-  const int bid = blockIdx.x;
-  const int run = bid >> 3;
-  const int item = (bid & 7) * a.chunk + run;
-  if (run >= a.chunk || item >= a.total) return;
-  // (integer division runs on the VALU: tell the compiler the result is uniform)
-  const int b = __builtin_amdgcn_readfirstlane(item / a.tiles);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n0 = (item - b * a.tiles) * a.tile_vox + wave * kWaveVox;  // wave's first voxel
-  if (n0 >= a.N) return;
-  const int CPB = a.CP * 4;
-
+  constexpr int CPB = L * 16;  // bytes per texel: CP = 4 L channels (host-checked)
   // wave-private LDS: 2 x 64 records of (4 texel offsets, 4 weights): the view
   // being gathered and the view being projected
-  unsigned char* wbase = smem + (size_t)wave * wave_lds_bytes(L);
   u32x4* s_off = reinterpret_cast<u32x4*>(wbase);
   float4* s_wt = reinterpret_cast<float4*>(wbase + (size_t)kWaveVox * 32);
-
-  int frame = b;
-  if (MODE == MODE_WINDOW && a.win_frame != nullptr) frame = uniform_load(a.win_frame, b);
-  const bool dead = (a.live != nullptr && uniform_load_u8(a.live, b) == 0) ||
-                    (unsigned)frame >= (unsigned)a.F;
   const int n = n0 + lane;  // phase A: this lane's voxel
-  if (dead) {
-    if (n < a.N) {
-      for (int ch = 0; ch < a.C; ch++) a.cubes[((long long)b * a.C + ch) * a.N + n] = 0.0f;
-      if (a.grids != nullptr) {
-        float* g = a.grids + ((long long)b * a.N + n) * 3;
-        g[0] = g[1] = g[2] = 0.0f;
-      }
-      if (a.mask != nullptr) {
-        uint8_t* m = (uint8_t*)a.mask + ((long long)b * a.N + n) * a.mask_bytes;
-        for (int k = 0; k < a.mask_bytes; k++) m[k] = 0;
-      }
-    }
-    return;
-  }
 
   float x = 0.f, y = 0.f, z = 0.f;
   const bool have = n < a.N && voxel_world<MODE>(a, b, n, &x, &y, &z);
@@ -274,7 +324,8 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
       // are finite, so its (all-zero) texels mix to 0
       const bool x0ok = need && (unsigned)t.x0 < (unsigned)a.W;
       const bool x1ok = need && (unsigned)(t.x0 + 1) < (unsigned)a.W;
-      const unsigned base = (unsigned)((t.y0 * a.W + t.x0) * CPB);
+      // 24-bit multiply-add (full rate; y0 and W are far below 2^23)
+      const unsigned base = (unsigned)(texel_index(t.y0, a.W, t.x0) * CPB);
       const unsigned row = (unsigned)(a.W * CPB);
       u32x4 off;
       off.x = x0ok ? base : kInvalid;
@@ -457,12 +508,209 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  if (n < a.N) {
+}
+
+template <int MODE, int L, int SB, int UNF>
+__global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+
+  // XCD-aware work order: workgroups b, b+8, b+16.. share an XCD (and its L2);
+  // give each such group one contiguous run of (batch item, tile) pairs so an
+  // XCD's L2 holds the heatmaps of one frame at a time.
+  const int bid = blockIdx.x;
+  const int run = bid >> 3;
+  const int item = (bid & 7) * a.chunk + run;
+  if (run >= a.chunk || item >= a.total) return;
+  // (integer division runs on the VALU: tell the compiler the result is uniform)
+  const int b = __builtin_amdgcn_readfirstlane(item / a.tiles);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = (item - b * a.tiles) * a.tile_vox + wave * kWaveVox;  // wave's first voxel
+  if (n0 >= a.N) return;
+  unsigned char* wbase = smem + (size_t)wave * wave_lds_bytes(L);
+
+  int frame = b;
+  if (MODE == MODE_WINDOW && a.win_frame != nullptr) frame = uniform_load(a.win_frame, b);
+  const bool dead = (a.live != nullptr && uniform_load_u8(a.live, b) == 0) ||
+                    (unsigned)frame >= (unsigned)a.F;
+  const int n = n0 + lane;  // phase A: this lane's voxel
+  if (dead) {
+    if (n < a.N) {
+      if (a.cubes != nullptr)
+        for (int ch = 0; ch < a.C; ch++) a.cubes[((long long)b * a.C + ch) * a.N + n] = 0.0f;
+      if (a.grids != nullptr) {
+        float* g = a.grids + ((long long)b * a.N + n) * 3;
+        g[0] = g[1] = g[2] = 0.0f;
+      }
+      if (a.mask != nullptr) {
+        uint8_t* m = (uint8_t*)a.mask + ((long long)b * a.N + n) * a.mask_bytes;
+        for (int k = 0; k < a.mask_bytes; k++) m[k] = 0;
+      }
+    }
+    return;
+  }
+
+  unproject_wave<MODE, L, SB, UNF>(a, b, frame, n0, lane, wbase);
+  constexpr int TSTR = kWaveVox + 1;
+  const float* s_out = reinterpret_cast<const float*>(wbase);
+  if (n < a.N && a.cubes != nullptr) {
     float* dst = a.cubes + (long long)b * a.C * a.N + n;
 #if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 2  // (almost) no stores
     if (s_out[lane] == 123.456f)
 #endif
     for (int ch = 0; ch < a.C; ch++) dst[(long long)ch * a.N] = s_out[ch * TSTR + lane];
+  }
+  if (a.pl01 != nullptr || a.pl02 != nullptr || a.pl12 != nullptr)
+    planes_epilogue(a, b, n0, lane, s_out, TSTR);
+}
+
+// --------------------------------------------- window + axis-max planes, fused
+// 64-voxel columns (VZ == 64).  A workgroup is kPlaneWaves waves = neighbouring y
+// of one window; every wave walks kPlaneXR columns along x, so that
+//   max over z  is a reduction over the wave's tile (one plain store per channel),
+//   max over x  is a running maximum in registers, one global atomic max per
+//               channel at the end of the walk (1/kPlaneXR per column),
+//   max over y  goes through LDS atomics into per-workgroup accumulators that
+//               are flushed every kPlaneXB columns with one global atomic max per
+//               (x, channel) row (1/kPlaneWaves per column).
+// The work order keeps one window per XCD at a time, like unproject_kernel.
+// (One global atomic per column, channel and plane -- the generic
+// planes_epilogue -- doubles the kernel time: the L2 executes about one atomic
+// lane per clock and channel.)
+#ifndef TEMPO_PL_WAVES
+#define TEMPO_PL_WAVES 4
+#endif
+#ifndef TEMPO_PL_XB
+#define TEMPO_PL_XB 4
+#endif
+#ifndef TEMPO_PL_XR
+#define TEMPO_PL_XR 8
+#endif
+#ifndef TEMPO_PL_SB
+#define TEMPO_PL_SB 2
+#endif
+constexpr int kPlaneXR = TEMPO_PL_XR;  // columns a wave walks along x
+constexpr int kPlaneWaves = TEMPO_PL_WAVES;
+constexpr int kPlaneXB = TEMPO_PL_XB;
+constexpr int plane_lds_bytes(int L) {
+  return kPlaneWaves * wave_lds_bytes(L) + kPlaneXB * 4 * L * kWaveVox * 4;
+}
+
+template <int L, int UNF>
+__global__ __launch_bounds__(kPlaneWaves * 64) void unproject_planes_kernel(
+    const UnprojArgs a) {
+  constexpr int SB = TEMPO_PL_SB;  // two sub-steps of fetches in flight (fewer waves fit here)
+  constexpr int CH = 4 * L;
+  constexpr int TSTR = kWaveVox + 1;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int bid = blockIdx.x;
+  const int run = bid >> 3;
+  const int item = (bid & 7) * a.chunk + run;  // XCD-aware order, as unproject_kernel
+  if (run >= a.chunk || item >= a.total) return;
+  const int VX = a.dim[0], VY = a.dim[1];
+  const int yblocks = VY / kPlaneWaves;
+  const int xblocks = (VX + kPlaneXR - 1) / kPlaneXR;
+  const int per_win = yblocks * xblocks;
+  const int b = __builtin_amdgcn_readfirstlane(item / per_win);
+  const int rem = item - b * per_win;
+  const int xb = __builtin_amdgcn_readfirstlane(rem / yblocks);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int y = (rem - xb * yblocks) * kPlaneWaves + wave;
+  const int x_begin = xb * kPlaneXR;
+  const int x_end = x_begin + kPlaneXR < VX ? x_begin + kPlaneXR : VX;
+  unsigned char* wbase = smem + (size_t)wave * wave_lds_bytes(L);
+  unsigned* acc = reinterpret_cast<unsigned*>(smem + (size_t)kPlaneWaves * wave_lds_bytes(L));
+
+  int frame = b;
+  if (a.win_frame != nullptr) frame = uniform_load(a.win_frame, b);
+  const bool dead = (a.live != nullptr && uniform_load_u8(a.live, b) == 0) ||
+                    (unsigned)frame >= (unsigned)a.F;
+  if (dead) {  // the planes were cleared by the host; the volume is zero-filled here
+    if (a.cubes != nullptr)
+      for (int x = x_begin; x < x_end; x++)
+        for (int ch = 0; ch < a.C; ch++)
+          a.cubes[((long long)b * a.C + ch) * a.N + (x * VY + y) * kWaveVox + lane] = 0.0f;
+    return;
+  }
+  for (int r = wave; r < kPlaneXB * CH; r += kPlaneWaves) acc[r * kWaveVox + lane] = 0u;
+  __syncthreads();
+
+  const long long bc = (long long)b * a.C;
+  unsigned over_x[CH];
+#pragma unroll
+  for (int ch = 0; ch < CH; ch++) over_x[ch] = 0u;
+  const float* s_out = reinterpret_cast<const float*>(wbase);
+#pragma unroll 1
+  for (int x = x_begin; x < x_end; x++) {
+    const int n0 = (x * VY + y) * kWaveVox;
+    unproject_wave<MODE_WINDOW, L, SB, UNF>(a, b, frame, n0, lane, wbase);
+    if (a.cubes != nullptr) {
+      float* dst = a.cubes + (long long)b * a.C * a.N + n0 + lane;
+      for (int ch = 0; ch < a.C; ch++) dst[(long long)ch * a.N] = s_out[ch * TSTR + lane];
+    }
+    const int xs = (x - x_begin) % kPlaneXB;
+#ifndef TEMPO_PL_ABL
+#define TEMPO_PL_ABL 0
+#endif
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+      if ((ch & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // four rows in flight, not CH
+      const unsigned v = __float_as_uint(s_out[ch * TSTR + lane]);
+      over_x[ch] = v > over_x[ch] ? v : over_x[ch];
+      if (v != 0u && !(TEMPO_PL_ABL & 1))
+        __hip_atomic_fetch_max(acc + (xs * CH + ch) * kWaveVox + lane, v, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (a.pl01 != nullptr && !(TEMPO_PL_ABL & 2)) {
+      // max over z: four lanes per channel row of the tile, 16 voxels each, then
+      // the quad is combined (16 channels per pass)
+#pragma unroll
+      for (int c0 = 0; c0 < CH; c0 += 16) {
+        const int ch = c0 + (lane >> 2);
+        const float* row = s_out + (ch < CH ? ch : 0) * TSTR + (lane & 3) * 16;
+        unsigned m = 0u;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+          const unsigned v = __float_as_uint(row[k]);
+          m = v > m ? v : m;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, true);
+        m = o > m ? o : m;  // quad_perm:[1,0,3,2]
+        o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, true);
+        m = o > m ? o : m;  // quad_perm:[2,3,0,1]
+        if ((lane & 3) == 0 && ch < a.C) a.pl01[((bc + ch) * VX + x) * VY + y] = m;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if ((xs == kPlaneXB - 1 || x == x_end - 1) && !(TEMPO_PL_ABL & 1)) {
+      __syncthreads();
+      for (int r = wave; r < (xs + 1) * CH; r += kPlaneWaves) {
+        const int rx = r / CH, ch = r - rx * CH;
+        const unsigned v = acc[r * kWaveVox + lane];
+        acc[r * kWaveVox + lane] = 0u;
+        if (v != 0u && ch < a.C && a.pl02 != nullptr)
+          __hip_atomic_fetch_max(a.pl02 + ((bc + ch) * VX + (x - xs + rx)) * kWaveVox + lane,
+                                 v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+    }
+  }
+  if (a.pl12 != nullptr) {
+#pragma unroll
+    for (int ch = 0; ch < CH; ch++) {
+      if (ch >= a.C) continue;
+      unsigned* dst = a.pl12 + ((bc + ch) * VY + y) * kWaveVox + lane;
+      if (xblocks == 1) *dst = over_x[ch];  // this wave owns (window, y) entirely
+      else if (over_x[ch] != 0u)
+        __hip_atomic_fetch_max(dst, over_x[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -511,7 +759,7 @@ __global__ __launch_bounds__(kThreads) void unproject_group_kernel(const UnprojA
   const int n0 = (item - grp * a.tiles) * a.tile_vox + wave * kWaveVox;
   if (n0 >= a.N) return;
   const int n = n0 + lane;
-  const int CPB = a.CP * 4;
+  constexpr int CPB = L * 16;  // bytes per texel: CP = 4 L channels (host-checked)
 
   unsigned char* wbase = smem + (size_t)wave * a.wave_lds;
   GroupRec* s_rec = reinterpret_cast<GroupRec*>(wbase);  // [V][64]
@@ -561,7 +809,7 @@ __global__ __launch_bounds__(kThreads) void unproject_group_kernel(const UnprojA
         int x0, y0;
         tempo_bilinear_frac(gx, gy, a.W, a.H, &x0, &y0, &fw, &fn);
         GroupRec r;
-        r.base = (unsigned)((y0 * a.W + x0) * CPB);
+        r.base = (unsigned)(texel_index(y0, a.W, x0) * CPB);
         r.flags = ((need && (unsigned)x0 < (unsigned)a.W) ? 1u : 0u) |
                   ((need && (unsigned)(x0 + 1) < (unsigned)a.W) ? 2u : 0u);
         r.w = fw;
@@ -863,12 +1111,6 @@ __global__ __launch_bounds__(kThreads) void project_points_kernel(
 // ------------------------------------------------------------ host helpers
 template <int MODE, int L, int UNF>
 int launch_one(const UnprojArgs& a, hipStream_t stream) {
-#ifndef TEMPO_SB_ROOT
-#define TEMPO_SB_ROOT 8
-#endif
-#ifndef TEMPO_SB_WINDOW
-#define TEMPO_SB_WINDOW 1
-#endif
   // sub-steps whose fetches are in flight together (8 = all of a view's)
   constexpr int SB = MODE == MODE_ROOT ? TEMPO_SB_ROOT : TEMPO_SB_WINDOW;
   UnprojArgs k = a;
@@ -884,6 +1126,18 @@ int launch_one(const UnprojArgs& a, hipStream_t stream) {
   const int waves = kThreads / 64;
   k.tile_vox = waves * kWaveVox;
   k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
+  const bool planes = a.pl01 != nullptr || a.pl02 != nullptr || a.pl12 != nullptr;
+  if (MODE == MODE_WINDOW && planes && a.dim[2] == kWaveVox && a.dim[1] % kPlaneWaves == 0 &&
+      plane_lds_bytes(L) <= 65536) {
+    const long long wtotal = (long long)a.NB * (a.dim[1] / kPlaneWaves) *
+                             ((a.dim[0] + kPlaneXR - 1) / kPlaneXR);
+    if (wtotal > 0x7fffffffLL / 8) return TEMPO_E_DIM;
+    k.total = (int)wtotal;
+    k.chunk = (k.total + 7) / 8;
+    hipLaunchKernelGGL((unproject_planes_kernel<L, UNF>), dim3(8 * k.chunk),
+                       dim3(kPlaneWaves * 64), (size_t)plane_lds_bytes(L), stream, k);
+    return (int)hipGetLastError();
+  }
   // grouped launch when the records of all views fit the default LDS limit;
   // otherwise the group table is only a hint and every item projects for itself
   if (a.groups != nullptr && waves * group_wave_lds(a.V, L) <= 65536) {
@@ -934,6 +1188,14 @@ int check_common(int V, int C, int CP, int H, int W) {
   if ((long long)H * W * CP * 4 >= 0x80000000LL) return TEMPO_E_SIZE;
   return TEMPO_OK;
 }
+
+int window_impl(const float* hm, const float* cam, const int32_t* win_frame, const float* fx,
+                const float* fy, const float* fz, const int32_t* tl, const int32_t* start,
+                const int32_t* end, const uint8_t* live, float* cubes, float* plane_xy,
+                float* plane_xz, float* plane_yz, int NW, int F, int V, int C, int CP, int H,
+                int W, int FX, int FY, int FZ, int VX, int VY, int VZ, float hm_w, float hm_h,
+                float img_w, float img_h, int mm_unfused, const int32_t* groups,
+                int num_groups, void* stream);
 
 }  // namespace
 
@@ -1063,8 +1325,39 @@ int tempo_unproject_window_grouped(const float* hm, const float* cam,
                                    int VX, int VY, int VZ, float hm_w, float hm_h,
                                    float img_w, float img_h, int mm_unfused,
                                    const int32_t* groups, int num_groups, void* stream) {
-  if (!hm || !cam || !fx || !fy || !fz || !tl || !start || !end || !cubes)
-    return TEMPO_E_NULL;
+  if (!cubes) return TEMPO_E_NULL;
+  return window_impl(hm, cam, win_frame, fx, fy, fz, tl, start, end, live, cubes, nullptr,
+                     nullptr, nullptr, NW, F, V, C, CP, H, W, FX, FY, FZ, VX, VY, VZ, hm_w,
+                     hm_h, img_w, img_h, mm_unfused, groups, num_groups, stream);
+}
+
+int tempo_unproject_window_planes(const float* hm, const float* cam,
+                                  const int32_t* win_frame, const float* fx,
+                                  const float* fy, const float* fz, const int32_t* tl,
+                                  const int32_t* start, const int32_t* end,
+                                  const uint8_t* live, float* cubes, float* plane_xy,
+                                  float* plane_xz, float* plane_yz, int NW, int F, int V,
+                                  int C, int CP, int H, int W, int FX, int FY, int FZ, int VX,
+                                  int VY, int VZ, float hm_w, float hm_h, float img_w,
+                                  float img_h, int mm_unfused, void* stream) {
+  if (!cubes && !plane_xy && !plane_xz && !plane_yz) return TEMPO_E_NULL;
+  return window_impl(hm, cam, win_frame, fx, fy, fz, tl, start, end, live, cubes, plane_xy,
+                     plane_xz, plane_yz, NW, F, V, C, CP, H, W, FX, FY, FZ, VX, VY, VZ, hm_w,
+                     hm_h, img_w, img_h, mm_unfused, nullptr, 0, stream);
+}
+
+}  // extern "C"
+
+namespace {
+
+int window_impl(const float* hm, const float* cam, const int32_t* win_frame, const float* fx,
+                const float* fy, const float* fz, const int32_t* tl, const int32_t* start,
+                const int32_t* end, const uint8_t* live, float* cubes, float* plane_xy,
+                float* plane_xz, float* plane_yz, int NW, int F, int V, int C, int CP, int H,
+                int W, int FX, int FY, int FZ, int VX, int VY, int VZ, float hm_w, float hm_h,
+                float img_w, float img_h, int mm_unfused, const int32_t* groups,
+                int num_groups, void* stream) {
+  if (!hm || !cam || !fx || !fy || !fz || !tl || !start || !end) return TEMPO_E_NULL;
   if ((groups == nullptr) != (num_groups == 0) || num_groups < 0 || num_groups > NW)
     return TEMPO_E_ARG;
   const int rc = check_common(V, C, CP, H, W);
@@ -1086,8 +1379,24 @@ int tempo_unproject_window_grouped(const float* hm, const float* cam,
   a.fdim[0] = FX; a.fdim[1] = FY; a.fdim[2] = FZ;
   a.geom = tempo_make_geom(hm_w, hm_h, img_w, img_h);
   a.groups = groups; a.NG = num_groups;
+  // the planes are max-accumulated: they start at +0.0, the smallest clamped value
+  const size_t nc = (size_t)NW * C * sizeof(float);
+  float* const pl[3] = {plane_xy, plane_xz, plane_yz};
+  const size_t pln[3] = {nc * VX * VY, nc * VX * VZ, nc * VY * VZ};
+  for (int i = 0; i < 3; i++) {
+    if (pl[i] == nullptr) continue;
+    const hipError_t e = hipMemsetAsync(pl[i], 0, pln[i], (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+  }
+  a.pl01 = reinterpret_cast<unsigned*>(plane_xy);
+  a.pl02 = reinterpret_cast<unsigned*>(plane_xz);
+  a.pl12 = reinterpret_cast<unsigned*>(plane_yz);
   return launch_mode<MODE_WINDOW>(a, mm_unfused, (hipStream_t)stream);
 }
+
+}  // namespace
+
+extern "C" {
 
 int tempo_project_points(const float* pts, const float* cam, int M, int N, float hm_w,
                          float hm_h, float img_w, float img_h, int mm_unfused, float* pix,

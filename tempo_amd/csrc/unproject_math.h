@@ -46,6 +46,16 @@ enum { CAM_FLOATS = 32 };
 // flavour bits of the three matmul sites (argument `mm_unfused` of the ABI)
 enum { TEMPO_UNFUSED_R = 1, TEMPO_UNFUSED_K = 2, TEMPO_UNFUSED_A = 4, TEMPO_UNFUSED_ALL = 7 };
 
+// Rare slow paths (numerators outside the range the fast division is proven for)
+// must stay behind a branch: left as a plain `if`, the compiler if-converts them
+// and every lane pays for the full IEEE division (div_scale/rcp/div_fmas/
+// div_fixup) on every call.  A wave-level test keeps the branch uniform.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define TEMPO_ANY_LANE(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+#else
+#define TEMPO_ANY_LANE(c) (c)
+#endif
+
 // ---- pairs: the x and y coordinate go through identical operation chains, so
 // they are carried as 2-vectors; on gfx950 these become packed-fp32 VALU ops
 // (v_pk_mul/add/fma_f32: two lanes' worth per issue slot)
@@ -98,8 +108,11 @@ TEMPO_HD tempo_f2 tempo_div_const2(tempo_f2 a, tempo_f2 b, tempo_f2 rb) {
   const float m0 = fabsf(a[0]), m1 = fabsf(a[1]);
   const int ok0 = (m0 == 0.0f) | ((m0 >= 0x1p-100f) & (m0 <= 0x1p100f));
   const int ok1 = (m1 == 0.0f) | ((m1 >= 0x1p-100f) & (m1 <= 0x1p100f));
-  if (!(ok0 & ok1))
-    q = a / b;
+  const int bad = !(ok0 & ok1);
+  if (TEMPO_ANY_LANE(bad)) {
+    const tempo_f2 slow = a / b;
+    if (bad) q = slow;
+  }
   return q;
 }
 
@@ -136,7 +149,11 @@ TEMPO_HD tempo_f2 tempo_div_shared2(tempo_f2 a, float b, float rcp_est) {
   q = TEMPO_FMA2(r, rb, q);
   const float m0 = fabsf(a[0]), m1 = fabsf(a[1]), mb = fabsf(b);
   const float hi = fmaxf(fmaxf(m0, m1), mb), lo = fminf(fminf(m0, m1), mb);
-  if (!(hi <= 0x1p60f) || !(lo >= 0x1p-60f)) q = a / tempo_splat(b);
+  const int bad = !(hi <= 0x1p60f) || !(lo >= 0x1p-60f);
+  if (TEMPO_ANY_LANE(bad)) {
+    const tempo_f2 slow = a / tempo_splat(b);
+    if (bad) q = slow;
+  }
   return q;
 }
 TEMPO_HD float tempo_rcp_est(float b) {

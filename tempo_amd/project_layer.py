@@ -74,7 +74,9 @@ class ProjectLayer(nn.Module):
         self.materialize_grids = True  # the reference's 2nd return; callers drop it
         # batch items with bit-identical camera records and grid centre (frames of
         # one recording) share one projection per voxel; results do not change
-        self.share_projection = True
+        # (opt-in: on MI355X the root kernel is bound by the texel gather, not by the
+        # projection arithmetic, and the grouped launch measured slower -- DESIGN.md)
+        self.share_projection = False
 
     def compute_grid(self, box_size, box_center, num_bins, device=None):
         """``project_layer.py:43-63``: ``[N,3]`` voxel centres, z fastest."""
@@ -285,6 +287,46 @@ class ProjectLayerWithMask(nn.Module):
             if cs != C:
                 cubes[:, c0:c0 + cs] = out
         return cubes, offset
+
+    def get_planes(self, feature_maps, grid_center, centers, scales, cameras,
+                   want_cubes=False):
+        """Extension: the three axis-max planes the pose regressor
+        takes from the window volume (``tempo_pose.py:172-176``), computed inside the
+        unprojection kernel.  Call ``set_space_size`` first (as ``forward`` does).
+        Returns ``(plane_xy [B,C,X,Y], plane_xz [B,C,X,Z], plane_yz [B,C,Y,Z], offset,
+        cubes | None)``; with ``want_cubes=False`` the ``[B,C,X,Y,Z]`` volume is never
+        written to memory."""
+        device = _check_inputs(feature_maps)
+        B, C = feature_maps[0].shape[:2]
+        if grid_center.device != device:
+            grid_center = grid_center.to(device)
+        centers_tl, offset, start, end = self.window_geometry(grid_center)
+        self._ensure_grids(device)
+        live = None
+        if grid_center.shape[1] != 3:
+            live = (grid_center[:, 3] >= 0).to(torch.uint8).contiguous()
+        cam = pack_cameras(centers, scales, cameras, self.image_size,
+                           self.mm_mode).to(device)
+        tl, st, en = (t.to(torch.int32).contiguous() for t in (centers_tl, start, end))
+        vx, vy, vz = self._sub_cube
+        cubes = (torch.empty(B, C, vx, vy, vz, dtype=torch.float32, device=device)
+                 if want_cubes else None)
+        planes = [torch.empty(B, C, *sh, dtype=torch.float32, device=device)
+                  for sh in ((vx, vy), (vx, vz), (vy, vz))]
+        for c0, cs in _Slices(C).items:
+            hm = ops.repack_nhwc(feature_maps, c0, cs)
+            whole = cs == C
+            out = ops.unproject_window_planes(
+                hm, cam, self._fine_axes, tl, st, en, self._sub_cube, cs,
+                self.heatmap_size, self.image_size, live=live, want_cubes=want_cubes,
+                mm_mode=self.mm_mode, out=cubes if whole else None,
+                planes_out=planes if whole else None)
+            if not whole:
+                if want_cubes:
+                    cubes[:, c0:c0 + cs] = out[0]
+                for dst, src in zip(planes, out[1:]):
+                    dst[:, c0:c0 + cs] = src
+        return planes[0], planes[1], planes[2], offset, cubes
 
     def forward(self, feature_maps, grid_center, space_center, space_size,
                 sub_space_size, sub_cube_size, centers, scales, cameras):

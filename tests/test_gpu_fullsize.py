@@ -88,6 +88,14 @@ def test_window_full_64_cubed(gpu_device):
     print(f'\n[window 64^3] max-abs {err:.3e}, differing {int((got.cpu() != ref).sum())}')
     assert err <= TOL
     assert torch.equal(off.cpu(), ref_off)
+    # fused axis-max planes (64-voxel columns: the in-wave reduction path), volume skipped
+    with torch.no_grad():
+        pxy, pxz, pyz, _, none = layer.get_planes(dcase['args'][0], dcase['args'][1],
+                                                  *dcase['args'][6:])
+    assert none is None
+    for p, dim in ((pxy, 4), (pxz, 3), (pyz, 2)):
+        assert torch.equal(torch.nan_to_num(p, nan=-1.0), torch.nan_to_num(got.max(dim=dim)[0], nan=-1.0))
+        assert _maxabs(torch.nan_to_num(p.cpu(), nan=-1.0), torch.nan_to_num(ref.max(dim=dim)[0], nan=-1.0)) <= TOL
 
 
 def test_h36m_window_config4_reduced(gpu_device):

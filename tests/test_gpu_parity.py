@@ -230,3 +230,35 @@ def test_window_shared_projection_equals_per_item(cfgname, gpu_device):
                            c3(centers), c3(scales), c3(cameras))
         got = a.view(P, T, *a.shape[1:])[:, t].cpu()
         assert float((got - ref).abs().max()) <= TOL
+
+
+def _planes_ref(cubes):
+    return cubes.max(dim=4)[0], cubes.max(dim=3)[0], cubes.max(dim=2)[0]
+
+
+@pytest.mark.parametrize('name', list(cases.WINDOW_CASES))
+@pytest.mark.parametrize('want_cubes', [False, True])
+def test_window_planes_equal_axis_max(name, want_cubes, gpu_device):
+    """Fused epilogue (tempo_pose.py:172-176): the three planes are bit-identical to
+    torch.max over the volume -- the HIP volume and, within TOL, the oracle's."""
+    import tempo_amd
+    case = cases.build_window(name)
+    dcase = cases.to_device(case, gpu_device)
+    layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    with torch.no_grad():
+        cubes, off = layer(*dcase['args'])
+        fms, gc = dcase['args'][0], dcase['args'][1]
+        pxy, pxz, pyz, off2, cubes2 = layer.get_planes(fms, gc, *dcase['args'][6:],
+                                                       want_cubes=want_cubes)
+    torch.cuda.synchronize()
+    assert torch.equal(off, off2)
+    assert (cubes2 is not None) == want_cubes
+    if want_cubes:
+        assert torch.equal(cubes, cubes2)
+    for got, ref in zip((pxy, pxz, pyz), _planes_ref(cubes)):
+        assert got.shape == ref.shape
+        assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(ref, nan=-1.0))
+    ref_layer = O.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, _ = ref_layer(*case['args'])
+    for got, ref in zip((pxy, pxz, pyz), _planes_ref(ref_cubes)):
+        assert float((got.cpu() - ref).abs().max()) <= TOL
