@@ -268,12 +268,12 @@ def measured_traffic(args, wl):
     face value (calibration: profiles/r01/fetch_size_calibration.txt)."""
     import csv
     if (args.workload == 'window_h36m' or (args.timesteps or 1) != 1 or args.calibrations != 1
-            or args.planes != 'off' or args.share):
+            or args.planes == 'with' or args.share):
         return None, None
-    tag = 'root' if args.workload == 'root' else 'window'
+    tag = 'root' if args.workload == 'root' else ('planes' if args.planes == 'only' else 'window')
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01',
                         tag + '_pmc_summary.csv')
-    if args.batch != 32 or (tag == 'window' and args.proposals != 10) or not os.path.exists(path):
+    if args.batch != 32 or (tag != 'root' and args.proposals != 10) or not os.path.exists(path):
         return None, None
     vals = {}
     with open(path) as f:
