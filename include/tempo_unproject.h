@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define TEMPO_ABI_VERSION 2
+#define TEMPO_ABI_VERSION 3
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
@@ -182,6 +182,74 @@ int tempo_unproject_window_planes(const float* hm, const float* cam,
                                   int VX, int VY, int VZ, float hm_w, float hm_h,
                                   float img_w, float img_h, int mm_unfused,
                                   void* stream);
+
+/* ---- training: forward that records the clamp mask, and the backward pass.
+ * The reference trains through this layer (freeze_2d = False,
+ * configs/.../resnet_rnn_panoptic_cam5.py:133): autograd differentiates
+ * project_layer.py:128-151 (grid_sample -> * bounding -> sum / (count + 1e-6) ->
+ * clamp) and :278-378 with respect to the feature maps; cameras and grids carry
+ * no gradient.
+ *
+ * tempo_clamp_mask_words: 64-bit words of clamp mask per batch item / window for
+ * a grid of num_voxels voxels and CP padded channels (< 0: TEMPO_E_*).  The mask
+ * says where min <= x <= max held at the final clamp (torch.clamp's backward
+ * rule); its layout is private to the library. */
+int tempo_clamp_mask_words(int num_voxels, int CP);
+
+/* tempo_unproject_root / _window that also write clamp_mask
+ * [B or NW][tempo_clamp_mask_words(X*Y*Z, CP)] (device). */
+int tempo_unproject_root_train(const float* hm, const float* cam, const float* ax_x,
+                               const float* ax_y, const float* ax_z, int ax_batched,
+                               const uint8_t* live, float* cubes, float* grids,
+                               void* mask, int mask_bytes, int B, int V, int C, int CP,
+                               int H, int W, int X, int Y, int Z, float hm_w,
+                               float hm_h, float img_w, float img_h, int mm_unfused,
+                               uint64_t* clamp_mask, void* stream);
+int tempo_unproject_window_train(const float* hm, const float* cam,
+                                 const int32_t* win_frame, const float* fx,
+                                 const float* fy, const float* fz, const int32_t* tl,
+                                 const int32_t* start, const int32_t* end,
+                                 const uint8_t* live, float* cubes, int NW, int F,
+                                 int V, int C, int CP, int H, int W, int FX, int FY,
+                                 int FZ, int VX, int VY, int VZ, float hm_w,
+                                 float hm_h, float img_w, float img_h, int mm_unfused,
+                                 uint64_t* clamp_mask, void* stream);
+
+/* Backward of the two calls above with respect to the heatmaps.
+ *   grad_cubes : fp32 [B, C, X, Y, Z] / [NW, C, VX, VY, VZ], gradient of the loss
+ *                with respect to the volume
+ *   clamp_mask : as written by the matching *_train call (same geometry)
+ *   grad_hm    : out fp32 [B or F, V, H, W, CP] channel-last; cleared on `stream`,
+ *                then accumulated with fp32 atomics (windows of one frame add
+ *                up), so sums agree with autograd to rounding, not bit for bit.
+ *                tempo_unrepack_nchw turns it into per-view NCHW gradients.
+ * All other arguments as in the forward calls.  At most 12 views (TEMPO_E_DIM
+ * beyond: the per-view footprints of a tile are kept in LDS). */
+int tempo_unproject_root_backward(const float* grad_cubes, const float* cam,
+                                  const float* ax_x, const float* ax_y,
+                                  const float* ax_z, int ax_batched,
+                                  const uint8_t* live, const uint64_t* clamp_mask,
+                                  float* grad_hm, int B, int V, int C, int CP, int H,
+                                  int W, int X, int Y, int Z, float hm_w, float hm_h,
+                                  float img_w, float img_h, int mm_unfused,
+                                  void* stream);
+int tempo_unproject_window_backward(const float* grad_cubes, const float* cam,
+                                    const int32_t* win_frame, const float* fx,
+                                    const float* fy, const float* fz,
+                                    const int32_t* tl, const int32_t* start,
+                                    const int32_t* end, const uint8_t* live,
+                                    const uint64_t* clamp_mask, float* grad_hm,
+                                    int NW, int F, int V, int C, int CP, int H, int W,
+                                    int FX, int FY, int FZ, int VX, int VY, int VZ,
+                                    float hm_w, float hm_h, float img_w, float img_h,
+                                    int mm_unfused, void* stream);
+
+/* Inverse of tempo_repack_nhwc: channel-last [B, V, H, W, CP] -> channels
+ * [c_begin, c_begin + C) of V per-view fp32 [B, C_total, H, W] tensors
+ * (views: HOST array of V device pointers).  Other channels are not touched. */
+int tempo_unrepack_nchw(const float* in, void* const* views, int V, int B,
+                        int C_total, int c_begin, int C, int H, int W, int CP,
+                        void* stream);
 
 /* Projection only, for parity checks of the coordinate chain
  * (SimpleCameraTorch.world_to_pixel + project_layer.py:113-126):

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TEMPO_LIB') or os.path.join(_HERE, 'lib', 'libtempo_unproject.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_void_p, _c_int, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
@@ -32,6 +32,18 @@ SIGNATURES = {
                                        [_c_int, _c_void_p, _c_int, _c_void_p]),
     'tempo_unproject_window_planes': (_c_int, [_c_void_p] * 14 + [_c_int] * 13 +
                                       [_c_float] * 4 + [_c_int, _c_void_p]),
+    'tempo_clamp_mask_words': (_c_int, [_c_int, _c_int]),
+    'tempo_unproject_root_train': (_c_int, [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 4 +
+                                   [_c_int] * 10 + [_c_float] * 4 +
+                                   [_c_int, _c_void_p, _c_void_p]),
+    'tempo_unproject_window_train': (_c_int, [_c_void_p] * 11 + [_c_int] * 13 +
+                                     [_c_float] * 4 + [_c_int, _c_void_p, _c_void_p]),
+    'tempo_unproject_root_backward': (_c_int, [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 3 +
+                                      [_c_int] * 9 + [_c_float] * 4 + [_c_int, _c_void_p]),
+    'tempo_unproject_window_backward': (_c_int, [_c_void_p] * 12 + [_c_int] * 13 +
+                                        [_c_float] * 4 + [_c_int, _c_void_p]),
+    'tempo_unrepack_nchw': (_c_int, [_c_void_p, ctypes.POINTER(_c_void_p)] + [_c_int] * 8 +
+                            [_c_void_p]),
     'tempo_project_points': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int] +
                              [_c_float] * 4 + [_c_int] + [_c_void_p] * 4),
 }

@@ -47,6 +47,8 @@ constexpr int kWaveVox = 64;                // voxels per wave
 constexpr int wave_lds_bytes(int L) {
   return 4 * L * 65 * 4 > 4096 ? 4 * L * 65 * 4 : 4096;
 }
+// clamp-mask words per 64-voxel tile: one ballot per (sub-step, channel of the quad)
+constexpr int mask_words(int L) { return ((kWaveVox + 64 / L - 1) / (64 / L)) * 4; }
 constexpr unsigned kInvalid = 0x80000000u;  // >= any view's byte size (host-checked)
 constexpr int MODE_ROOT = 0;
 constexpr int MODE_WINDOW = 1;
@@ -87,6 +89,11 @@ struct UnprojArgs {
   unsigned* pl01;
   unsigned* pl02;
   unsigned* pl12;
+  // training: the forward records which elements the final clamp lets a gradient
+  // through (unclamped value in [0,1]); ballot words in the kernels' own lane
+  // layout, [NB][ceil(N/64)][mask_words(L)]
+  unsigned long long* cmask;
+  float* ghm;  // backward: gradient of the channel-last heatmaps, accumulated
   const int32_t* groups;  // grouped launch: [NG][2] = (first item, count), or nullptr
   int NG;
   int wave_lds;  // grouped launch: LDS bytes per wave
@@ -486,6 +493,22 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
     const f32x2 t = acc01[s] + acc23[s];
     const float u = t.x + t.y;
     odd |= u != u;
+  }
+  if (a.cmask != nullptr) {
+    // torch.clamp's backward passes the gradient where min <= x <= max (NaN: no)
+    unsigned long long* mw =
+        a.cmask + ((long long)b * ((a.N + kWaveVox - 1) / kWaveVox) + (n0 >> 6)) * mask_words(L);
+#pragma unroll
+    for (int s = 0; s < NSUB; s++) {
+      const bool live_el = lane_on && s * VPS + vq < kWaveVox;
+      const float e[4] = {acc01[s].x, acc01[s].y, acc23[s].x, acc23[s].y};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const unsigned long long bal =
+            __builtin_amdgcn_ballot_w64(live_el && e[j] >= 0.0f && e[j] <= 1.0f);
+        if (lane == 0) mw[s * 4 + j] = bal;
+      }
+    }
   }
   const bool slow = __builtin_amdgcn_ballot_w64(odd) != 0;
 #pragma unroll
@@ -1001,6 +1024,169 @@ __global__ __launch_bounds__(kThreads) void unproject_group_kernel(const UnprojA
   }
 }
 
+// ------------------------------------------------------------------ backward
+// Gradient of the volume with respect to the heatmaps (the only input with a
+// gradient: cameras and grids are constants).  Mirrors autograd through the
+// reference's op chain: clamp (mask recorded by the forward) -> division by
+// count + 1e-6 -> bounding mask -> grid_sample's backward, which adds
+// weight * gradient into the four texels of every sample.  Same tiling and lane
+// layout as unproject_kernel; every view is projected first (records in LDS, as
+// in the grouped launch), then each lane adds its four channels into the four
+// texels with hardware fp32 atomics.  The accumulation order is not fixed, so
+// results agree with autograd to rounding, not bit for bit.
+constexpr int backward_wave_lds(int V, int L) {
+  return V * kWaveVox * (int)sizeof(GroupRec) + kWaveVox * 4 + 4 * L * (kWaveVox + 1) * 4;
+}
+
+template <int MODE, int L, int UNF>
+__global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const UnprojArgs a) {
+  constexpr int VPS = 64 / L;
+  constexpr int NSUB = (kWaveVox + VPS - 1) / VPS;
+  constexpr int CPB = L * 16;
+  constexpr int TSTR = kWaveVox + 1;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int bid = blockIdx.x;
+  const int run = bid >> 3;
+  const int item = (bid & 7) * a.chunk + run;
+  if (run >= a.chunk || item >= a.total) return;
+  const int b = __builtin_amdgcn_readfirstlane(item / a.tiles);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = (item - b * a.tiles) * a.tile_vox + wave * kWaveVox;
+  if (n0 >= a.N) return;
+  const int n = n0 + lane;
+  int frame = b;
+  if (MODE == MODE_WINDOW && a.win_frame != nullptr) frame = uniform_load(a.win_frame, b);
+  if ((a.live != nullptr && uniform_load_u8(a.live, b) == 0) || (unsigned)frame >= (unsigned)a.F)
+    return;  // a skipped item's volume is constant zero: no gradient
+
+  unsigned char* wbase = smem + (size_t)wave * a.wave_lds;
+  GroupRec* s_rec = reinterpret_cast<GroupRec*>(wbase);  // [V][64]
+  float* s_den = reinterpret_cast<float*>(wbase + (size_t)a.V * kWaveVox * sizeof(GroupRec));
+  float* s_g = s_den + kWaveVox;  // [4L][TSTR] incoming gradient, lane = voxel
+
+  const float* gout = a.cubes + (long long)b * a.C * a.N;
+  for (int ch = 0; ch < 4 * L; ch++)
+    s_g[ch * TSTR + lane] = (ch < a.C && n < a.N) ? gout[(long long)ch * a.N + n] : 0.0f;
+
+  float x = 0.f, y = 0.f, z = 0.f;
+  const bool have = n < a.N && voxel_world<MODE>(a, b, n, &x, &y, &z);
+  int cnt = 0;
+  unsigned amask = 0;
+#pragma unroll 1
+  for (int slot = 0; slot < a.V; slot++) {
+    const int view = slot_view(a, slot);
+    const TempoCam cam = load_cam(a.cam, frame * a.V + view);
+    TempoPix p;
+    p.px = p.py = 0.f;
+    p.inside = 0;
+    bool need = false;
+    if (have) {
+      p = tempo_world_to_pixel(&cam, x, y, z, UNF);
+      need = MODE != MODE_ROOT || p.inside || p.px != p.px || p.py != p.py;
+    }
+    cnt += p.inside;
+    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+      float gx, gy, fw, fn;
+      int x0, y0;
+      tempo_pixel_to_grid(&cam, p.px, p.py, &a.geom, UNF, &gx, &gy);
+      tempo_bilinear_frac(gx, gy, a.W, a.H, &x0, &y0, &fw, &fn);
+      GroupRec r;
+      r.base = (unsigned)(texel_index(y0, a.W, x0) * CPB);
+      r.flags = ((need && (unsigned)x0 < (unsigned)a.W) ? 1u : 0u) |
+                ((need && (unsigned)(x0 + 1) < (unsigned)a.W) ? 2u : 0u);
+      r.w = fw;
+      r.n = fn;
+      s_rec[slot * kWaveVox + lane] = r;
+      amask |= 1u << slot;
+    }
+  }
+  amask = __builtin_amdgcn_readfirstlane(amask);
+  s_den[lane] = (MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  const bool lane_on = lane < VPS * L;
+  const int vq = lane / L;
+  const int cq = lane - vq * L;
+  const unsigned long long* mw =
+      a.cmask + ((long long)b * ((a.N + kWaveVox - 1) / kWaveVox) + (n0 >> 6)) * mask_words(L);
+  // d(volume)/d(masked view sum) per element: gradient / (count + 1e-6) where
+  // the clamp passes it, else 0
+  float gs[NSUB][4];
+#pragma unroll
+  for (int s = 0; s < NSUB; s++) {
+    const int vsl = s * VPS + vq;
+    const bool on = lane_on && vsl < kWaveVox;
+    const int rd = on ? vsl : 0;
+    const float den = s_den[rd];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const unsigned long long word = uniform_load(mw, s * 4 + j);
+      const bool pass = on && ((word >> lane) & 1ull) != 0;
+      gs[s][j] = pass ? s_g[(4 * cq + j) * TSTR + rd] / den : 0.0f;
+    }
+  }
+
+  const unsigned rowb = (unsigned)(a.W * CPB);
+  unsigned mm = amask;
+#pragma unroll 1
+  while (mm) {
+    const int slot = __builtin_ctz(mm);
+    mm &= mm - 1;
+    const int view = slot_view(a, slot);
+    char* vbase = reinterpret_cast<char*>(a.ghm + (long long)frame * a.frame_stride) +
+                  (long long)view * a.view_bytes + cq * 16;
+#pragma unroll
+    for (int s = 0; s < NSUB; s++) {
+      const int vsl = s * VPS + vq;
+      if (!(lane_on && vsl < kWaveVox)) continue;
+      const GroupRec r = s_rec[slot * kWaveVox + vsl];
+      if (r.flags == 0u) continue;
+      const float e = 1.0f - r.w, sth = 1.0f - r.n;
+      const float wt[4] = {sth * e, sth * r.w, r.n * e, r.n * r.w};
+      const unsigned off[4] = {r.base, r.base + CPB, r.base + rowb, r.base + rowb + CPB};
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        // column inside the map (flags) and row inside the map (byte range)
+        if (!((r.flags >> (t & 1)) & 1u) || off[t] >= a.view_bytes) continue;
+        float* dst = reinterpret_cast<float*>(vbase + off[t]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float v = gs[s][j] * wt[t];
+          if (v != 0.0f) unsafeAtomicAdd(dst + j, v);
+        }
+      }
+    }
+  }
+}
+
+// channel-last [B][V][HW][CP] -> per-view NCHW slices (inverse of the repack),
+// 64-pixel tiles
+struct UnrepackArgs {
+  float* views[TEMPO_MAX_VIEWS];
+  const float* in;
+  int V, B, C_total, c_begin, C, HW, CP;
+};
+
+__global__ __launch_bounds__(kThreads) void unrepack_kernel(const UnrepackArgs a) {
+  __shared__ float s[TEMPO_MAX_CHANNELS][64 + 1];
+  const int p0 = blockIdx.x * 64;
+  const int v = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* in = a.in + (((long long)b * a.V + v) * a.HW + p0) * a.CP;
+  for (int i = tid; i < 64 * a.CP; i += kThreads) {
+    const int px = i / a.CP, c = i - px * a.CP;
+    if (p0 + px < a.HW) s[c][px] = in[i];
+  }
+  __syncthreads();
+  float* out = a.views[v] + ((long long)b * a.C_total + a.c_begin) * a.HW;
+  for (int c = wave; c < a.C; c += 4)
+    if (p0 + lane < a.HW) out[(long long)c * a.HW + p0 + lane] = s[c][lane];
+}
+
 // ------------------------------------------------------------------ repack
 struct RepackArgs {
   const float* views[TEMPO_MAX_VIEWS];
@@ -1159,6 +1345,50 @@ int launch_one(const UnprojArgs& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+template <int MODE, int L, int UNF>
+int launch_backward_one(const UnprojArgs& a, hipStream_t stream) {
+  UnprojArgs k = a;
+  for (int i = 0; i < 2; i++) {
+    const unsigned long long m = 0x100000000ULL / (unsigned)a.dim[2 - i];
+    k.magic[i] = m > 0xffffffffULL ? 0xffffffffu : (unsigned)m;
+  }
+  for (int w = 0; w < 10; w++) k.order[w] = 0xffffffffu;
+  for (int sl = 0; sl < a.V; sl++) {
+    const unsigned v = (unsigned)tempo_view_of_slot(sl, a.V);
+    k.order[sl >> 2] = (k.order[sl >> 2] & ~(255u << ((sl & 3) * 8))) | (v << ((sl & 3) * 8));
+  }
+  const int waves = kThreads / 64;
+  k.tile_vox = waves * kWaveVox;
+  k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
+  k.wave_lds = backward_wave_lds(a.V, L);
+  if (waves * k.wave_lds > 65536) return TEMPO_E_DIM;  // too many views for the record table
+  const long long total = (long long)a.NB * k.tiles;
+  if (total > 0x7fffffffLL / 8) return TEMPO_E_DIM;
+  k.total = (int)total;
+  k.chunk = (k.total + 7) / 8;
+  hipLaunchKernelGGL((unproject_backward_kernel<MODE, L, UNF>), dim3(8 * k.chunk),
+                     dim3(kThreads), (size_t)waves * k.wave_lds, stream, k);
+  return (int)hipGetLastError();
+}
+
+template <int MODE>
+int launch_backward(const UnprojArgs& a, int mm_unfused, hipStream_t stream) {
+  if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
+#define TEMPO_BWD_CASE(LL)                                          \
+  case LL:                                                          \
+    return mm_unfused ? launch_backward_one<MODE, LL, 1>(a, stream) \
+                      : launch_backward_one<MODE, LL, 0>(a, stream);
+  switch (a.CP / 4) {
+    TEMPO_BWD_CASE(4)
+    TEMPO_BWD_CASE(5)
+    TEMPO_BWD_CASE(6)
+    TEMPO_BWD_CASE(7)
+    TEMPO_BWD_CASE(8)
+    default: return TEMPO_E_PAD;
+  }
+#undef TEMPO_BWD_CASE
+}
+
 template <int MODE, int UNF>
 int launch_l(const UnprojArgs& a, hipStream_t stream) {
   switch (a.CP / 4) {
@@ -1189,13 +1419,25 @@ int check_common(int V, int C, int CP, int H, int W) {
   return TEMPO_OK;
 }
 
+struct Extra {
+  unsigned long long* cmask = nullptr;  // forward: record / backward: read the clamp mask
+  float* ghm = nullptr;                 // backward: gradient of the heatmaps (accumulated)
+};
+
 int window_impl(const float* hm, const float* cam, const int32_t* win_frame, const float* fx,
                 const float* fy, const float* fz, const int32_t* tl, const int32_t* start,
                 const int32_t* end, const uint8_t* live, float* cubes, float* plane_xy,
                 float* plane_xz, float* plane_yz, int NW, int F, int V, int C, int CP, int H,
                 int W, int FX, int FY, int FZ, int VX, int VY, int VZ, float hm_w, float hm_h,
                 float img_w, float img_h, int mm_unfused, const int32_t* groups,
-                int num_groups, void* stream);
+                int num_groups, const Extra& ex, void* stream);
+
+int root_impl(const float* hm, const float* cam, const float* ax_x, const float* ax_y,
+              const float* ax_z, int ax_batched, const uint8_t* live, float* cubes,
+              float* grids, void* mask, int mask_bytes, int B, int V, int C, int CP, int H,
+              int W, int X, int Y, int Z, float hm_w, float hm_h, float img_w, float img_h,
+              int mm_unfused, const int32_t* groups, int num_groups, const Extra& ex,
+              void* stream);
 
 }  // namespace
 
@@ -1274,6 +1516,113 @@ int tempo_unproject_root_grouped(const float* hm, const float* cam, const float*
                                  int H, int W, int X, int Y, int Z, float hm_w, float hm_h,
                                  float img_w, float img_h, int mm_unfused,
                                  const int32_t* groups, int num_groups, void* stream) {
+  return root_impl(hm, cam, ax_x, ax_y, ax_z, ax_batched, live, cubes, grids, mask, mask_bytes,
+                   B, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w, img_h, mm_unfused, groups,
+                   num_groups, Extra(), stream);
+}
+
+int tempo_clamp_mask_words(int num_voxels, int CP) {
+  if (num_voxels <= 0) return TEMPO_E_DIM;
+  if (CP % 4 != 0 || CP < 16 || CP > TEMPO_MAX_CHANNELS) return TEMPO_E_PAD;
+  return (num_voxels + kWaveVox - 1) / kWaveVox * mask_words(CP / 4);
+}
+
+int tempo_unproject_root_train(const float* hm, const float* cam, const float* ax_x,
+                               const float* ax_y, const float* ax_z, int ax_batched,
+                               const uint8_t* live, float* cubes, float* grids, void* mask,
+                               int mask_bytes, int B, int V, int C, int CP, int H, int W,
+                               int X, int Y, int Z, float hm_w, float hm_h, float img_w,
+                               float img_h, int mm_unfused, uint64_t* clamp_mask,
+                               void* stream) {
+  if (!clamp_mask) return TEMPO_E_NULL;
+  Extra ex;
+  ex.cmask = reinterpret_cast<unsigned long long*>(clamp_mask);
+  return root_impl(hm, cam, ax_x, ax_y, ax_z, ax_batched, live, cubes, grids, mask, mask_bytes,
+                   B, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w, img_h, mm_unfused, nullptr, 0,
+                   ex, stream);
+}
+
+int tempo_unproject_root_backward(const float* grad_cubes, const float* cam,
+                                  const float* ax_x, const float* ax_y, const float* ax_z,
+                                  int ax_batched, const uint8_t* live,
+                                  const uint64_t* clamp_mask, float* grad_hm, int B, int V,
+                                  int C, int CP, int H, int W, int X, int Y, int Z,
+                                  float hm_w, float hm_h, float img_w, float img_h,
+                                  int mm_unfused, void* stream) {
+  if (!grad_cubes || !clamp_mask || !grad_hm) return TEMPO_E_NULL;
+  Extra ex;
+  ex.cmask = reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(clamp_mask));
+  ex.ghm = grad_hm;
+  return root_impl(grad_hm, cam, ax_x, ax_y, ax_z, ax_batched, live,
+                   const_cast<float*>(grad_cubes), nullptr, nullptr, 0, B, V, C, CP, H, W, X, Y,
+                   Z, hm_w, hm_h, img_w, img_h, mm_unfused, nullptr, 0, ex, stream);
+}
+
+int tempo_unproject_window_train(const float* hm, const float* cam, const int32_t* win_frame,
+                                 const float* fx, const float* fy, const float* fz,
+                                 const int32_t* tl, const int32_t* start, const int32_t* end,
+                                 const uint8_t* live, float* cubes, int NW, int F, int V,
+                                 int C, int CP, int H, int W, int FX, int FY, int FZ, int VX,
+                                 int VY, int VZ, float hm_w, float hm_h, float img_w,
+                                 float img_h, int mm_unfused, uint64_t* clamp_mask,
+                                 void* stream) {
+  if (!cubes || !clamp_mask) return TEMPO_E_NULL;
+  Extra ex;
+  ex.cmask = reinterpret_cast<unsigned long long*>(clamp_mask);
+  return window_impl(hm, cam, win_frame, fx, fy, fz, tl, start, end, live, cubes, nullptr,
+                     nullptr, nullptr, NW, F, V, C, CP, H, W, FX, FY, FZ, VX, VY, VZ, hm_w,
+                     hm_h, img_w, img_h, mm_unfused, nullptr, 0, ex, stream);
+}
+
+int tempo_unproject_window_backward(const float* grad_cubes, const float* cam,
+                                    const int32_t* win_frame, const float* fx,
+                                    const float* fy, const float* fz, const int32_t* tl,
+                                    const int32_t* start, const int32_t* end,
+                                    const uint8_t* live, const uint64_t* clamp_mask,
+                                    float* grad_hm, int NW, int F, int V, int C, int CP, int H,
+                                    int W, int FX, int FY, int FZ, int VX, int VY, int VZ,
+                                    float hm_w, float hm_h, float img_w, float img_h,
+                                    int mm_unfused, void* stream) {
+  if (!grad_cubes || !clamp_mask || !grad_hm) return TEMPO_E_NULL;
+  Extra ex;
+  ex.cmask = reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(clamp_mask));
+  ex.ghm = grad_hm;
+  return window_impl(grad_hm, cam, win_frame, fx, fy, fz, tl, start, end, live,
+                     const_cast<float*>(grad_cubes), nullptr, nullptr, nullptr, NW, F, V, C, CP,
+                     H, W, FX, FY, FZ, VX, VY, VZ, hm_w, hm_h, img_w, img_h, mm_unfused,
+                     nullptr, 0, ex, stream);
+}
+
+int tempo_unrepack_nchw(const float* in, void* const* views, int V, int B, int C_total,
+                        int c_begin, int C, int H, int W, int CP, void* stream) {
+  if (in == nullptr || views == nullptr) return TEMPO_E_NULL;
+  const int rc = check_common(V, C, CP, H, W);
+  if (rc != TEMPO_OK) return rc;
+  if (B <= 0 || B > 65535 || c_begin < 0 || c_begin + C > C_total) return TEMPO_E_DIM;
+  UnrepackArgs a;
+  for (int v = 0; v < TEMPO_MAX_VIEWS; v++) a.views[v] = nullptr;
+  for (int v = 0; v < V; v++) {
+    if (views[v] == nullptr) return TEMPO_E_NULL;
+    a.views[v] = static_cast<float*>(views[v]);
+  }
+  a.in = in;
+  a.V = V; a.B = B; a.C_total = C_total; a.c_begin = c_begin; a.C = C;
+  a.HW = H * W; a.CP = CP;
+  dim3 grid((a.HW + 63) / 64, V, B);
+  hipLaunchKernelGGL(unrepack_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"
+
+namespace {
+
+int root_impl(const float* hm, const float* cam, const float* ax_x, const float* ax_y,
+              const float* ax_z, int ax_batched, const uint8_t* live, float* cubes,
+              float* grids, void* mask, int mask_bytes, int B, int V, int C, int CP, int H,
+              int W, int X, int Y, int Z, float hm_w, float hm_h, float img_w, float img_h,
+              int mm_unfused, const int32_t* groups, int num_groups, const Extra& ex,
+              void* stream) {
   if (!hm || !cam || !ax_x || !ax_y || !ax_z || !cubes) return TEMPO_E_NULL;
   if ((groups == nullptr) != (num_groups == 0) || num_groups < 0 || num_groups > B)
     return TEMPO_E_ARG;
@@ -1300,8 +1649,20 @@ int tempo_unproject_root_grouped(const float* hm, const float* cam, const float*
   a.dim[0] = X; a.dim[1] = Y; a.dim[2] = Z; a.N = (int)N;
   a.geom = tempo_make_geom(hm_w, hm_h, img_w, img_h);
   a.groups = groups; a.NG = num_groups;
+  a.cmask = ex.cmask;
+  if (ex.ghm != nullptr) {  // backward: `cubes` is the incoming gradient
+    a.ghm = ex.ghm;
+    const hipError_t e = hipMemsetAsync(ex.ghm, 0, (size_t)B * a.frame_stride * sizeof(float),
+                                        (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return launch_backward<MODE_ROOT>(a, mm_unfused, (hipStream_t)stream);
+  }
   return launch_mode<MODE_ROOT>(a, mm_unfused, (hipStream_t)stream);
 }
+
+}  // namespace
+
+extern "C" {
 
 int tempo_unproject_window(const float* hm, const float* cam, const int32_t* win_frame,
                            const float* fx, const float* fy, const float* fz,
@@ -1328,7 +1689,7 @@ int tempo_unproject_window_grouped(const float* hm, const float* cam,
   if (!cubes) return TEMPO_E_NULL;
   return window_impl(hm, cam, win_frame, fx, fy, fz, tl, start, end, live, cubes, nullptr,
                      nullptr, nullptr, NW, F, V, C, CP, H, W, FX, FY, FZ, VX, VY, VZ, hm_w,
-                     hm_h, img_w, img_h, mm_unfused, groups, num_groups, stream);
+                     hm_h, img_w, img_h, mm_unfused, groups, num_groups, Extra(), stream);
 }
 
 int tempo_unproject_window_planes(const float* hm, const float* cam,
@@ -1343,7 +1704,7 @@ int tempo_unproject_window_planes(const float* hm, const float* cam,
   if (!cubes && !plane_xy && !plane_xz && !plane_yz) return TEMPO_E_NULL;
   return window_impl(hm, cam, win_frame, fx, fy, fz, tl, start, end, live, cubes, plane_xy,
                      plane_xz, plane_yz, NW, F, V, C, CP, H, W, FX, FY, FZ, VX, VY, VZ, hm_w,
-                     hm_h, img_w, img_h, mm_unfused, nullptr, 0, stream);
+                     hm_h, img_w, img_h, mm_unfused, nullptr, 0, Extra(), stream);
 }
 
 }  // extern "C"
@@ -1356,7 +1717,7 @@ int window_impl(const float* hm, const float* cam, const int32_t* win_frame, con
                 float* plane_xz, float* plane_yz, int NW, int F, int V, int C, int CP, int H,
                 int W, int FX, int FY, int FZ, int VX, int VY, int VZ, float hm_w, float hm_h,
                 float img_w, float img_h, int mm_unfused, const int32_t* groups,
-                int num_groups, void* stream) {
+                int num_groups, const Extra& ex, void* stream) {
   if (!hm || !cam || !fx || !fy || !fz || !tl || !start || !end) return TEMPO_E_NULL;
   if ((groups == nullptr) != (num_groups == 0) || num_groups < 0 || num_groups > NW)
     return TEMPO_E_ARG;
@@ -1391,6 +1752,14 @@ int window_impl(const float* hm, const float* cam, const int32_t* win_frame, con
   a.pl01 = reinterpret_cast<unsigned*>(plane_xy);
   a.pl02 = reinterpret_cast<unsigned*>(plane_xz);
   a.pl12 = reinterpret_cast<unsigned*>(plane_yz);
+  a.cmask = ex.cmask;
+  if (ex.ghm != nullptr) {  // backward: `cubes` is the incoming gradient
+    a.ghm = ex.ghm;
+    const hipError_t e = hipMemsetAsync(ex.ghm, 0, (size_t)F * a.frame_stride * sizeof(float),
+                                        (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return launch_backward<MODE_WINDOW>(a, mm_unfused, (hipStream_t)stream);
+  }
   return launch_mode<MODE_WINDOW>(a, mm_unfused, (hipStream_t)stream);
 }
 

@@ -106,9 +106,116 @@ def _groups_arg(groups, n_items, dev):
     return groups, int(groups.shape[0])
 
 
+def clamp_mask_words(num_voxels, cp):
+    n = _lib.load().tempo_clamp_mask_words(int(num_voxels), int(cp))
+    _lib.check(min(n, 0), 'tempo_clamp_mask_words')
+    return n
+
+
+def new_clamp_mask(items, num_voxels, cp, device):
+    """Buffer for the clamp mask a training forward records (int64 words)."""
+    return torch.empty(items, clamp_mask_words(num_voxels, cp), dtype=torch.int64, device=device)
+
+
+def _check_clamp_mask(t, items, num_voxels, cp, dev):
+    _need(t, torch.int64, 'clamp_mask', dev)
+    if t.numel() != items * clamp_mask_words(num_voxels, cp):
+        raise ValueError('clamp_mask has the wrong size (see new_clamp_mask)')
+
+
+def unrepack_nchw(hm, channels_total, c_begin=0, channels=None, out=None):
+    """Inverse of :func:`repack_nhwc`: ``[B,V,H,W,CP]`` -> list of V fp32
+    ``[B,channels_total,H,W]`` tensors (channels ``[c_begin, c_begin+channels)``
+    written; ``out`` = existing tensors to write into, else new zero tensors)."""
+    lib = _lib.load()
+    dev = hm.device
+    _need(hm, torch.float32, 'hm')
+    B, V, H, W, CP = hm.shape
+    C = channels_total - c_begin if channels is None else channels
+    if out is None:
+        out = [torch.zeros(B, channels_total, H, W, dtype=torch.float32, device=dev)
+               for _ in range(V)]
+    for i, t in enumerate(out):
+        _need(t, torch.float32, f'out[{i}]', dev)
+        if tuple(t.shape) != (B, channels_total, H, W):
+            raise ValueError('out tensors must be [B, channels_total, H, W]')
+    ptrs = (ctypes.c_void_p * V)(*[t.data_ptr() for t in out])
+    with torch.cuda.device(dev):
+        rc = lib.tempo_unrepack_nchw(_ptr(hm), ptrs, V, B, channels_total, c_begin, C, H, W,
+                                     CP, _stream_ptr(dev))
+    _lib.check(rc, 'tempo_unrepack_nchw')
+    return out
+
+
+def unproject_root_backward(grad_cubes, cam, axes, clamp_mask, hm_shape, heatmap_size,
+                            image_size, live=None, mm_mode='auto'):
+    """Gradient of :func:`unproject_root`'s volume with respect to the repacked
+    heatmaps: ``grad_cubes [B,C,X,Y,Z]`` -> ``[B,V,H,W,CP]`` (``hm_shape``).
+    ``clamp_mask`` is the one the training forward recorded."""
+    lib = _lib.load()
+    dev = grad_cubes.device
+    _need(grad_cubes, torch.float32, 'grad_cubes')
+    B, V, H, W, CP = (int(v) for v in hm_shape)
+    _need(cam, torch.float32, 'cam', dev)
+    ax = [_need(a, torch.float32, 'axes', dev) for a in axes]
+    batched = ax[0].dim() == 2
+    X, Y, Z = (int(a.shape[-1]) for a in ax)
+    C = int(grad_cubes.shape[1])
+    if tuple(grad_cubes.shape) != (B, C, X, Y, Z):
+        raise ValueError(f'grad_cubes must be [{B},C,{X},{Y},{Z}]')
+    _check_clamp_mask(clamp_mask, B, X * Y * Z, CP, dev)
+    if live is not None:
+        _need(live, torch.uint8, 'live', dev)
+    ghm = torch.empty(B, V, H, W, CP, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.tempo_unproject_root_backward(
+            _ptr(grad_cubes), _ptr(cam), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), int(batched),
+            _ptr(live), _ptr(clamp_mask), _ptr(ghm), B, V, C, CP, H, W, X, Y, Z,
+            float(heatmap_size[0]), float(heatmap_size[1]), float(image_size[0]),
+            float(image_size[1]), numerics.abi_flag(mm_mode), _stream_ptr(dev))
+    _lib.check(rc, 'tempo_unproject_root_backward')
+    return ghm
+
+
+def unproject_window_backward(grad_cubes, cam, fine_axes, tl, start, end, clamp_mask,
+                              hm_shape, heatmap_size, image_size, win_frame=None, live=None,
+                              mm_mode='auto'):
+    """Gradient of :func:`unproject_window`'s volume with respect to the repacked
+    heatmaps: ``grad_cubes [NW,C,VX,VY,VZ]`` -> ``[F,V,H,W,CP]``."""
+    lib = _lib.load()
+    dev = grad_cubes.device
+    _need(grad_cubes, torch.float32, 'grad_cubes')
+    F_, V, H, W, CP = (int(v) for v in hm_shape)
+    _need(cam, torch.float32, 'cam', dev)
+    fa = [_need(a, torch.float32, 'fine_axes', dev) for a in fine_axes]
+    NW, C, VX, VY, VZ = (int(v) for v in grad_cubes.shape)
+    for name, t in (('tl', tl), ('start', start), ('end', end)):
+        _need(t, torch.int32, name, dev)
+        if tuple(t.shape) != (NW, 3):
+            raise ValueError(f'{name} must be [{NW},3]')
+    if win_frame is not None:
+        _need(win_frame, torch.int32, 'win_frame', dev)
+    elif NW != F_:
+        raise ValueError('without win_frame there must be one window per frame')
+    if live is not None:
+        _need(live, torch.uint8, 'live', dev)
+    _check_clamp_mask(clamp_mask, NW, VX * VY * VZ, CP, dev)
+    ghm = torch.empty(F_, V, H, W, CP, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.tempo_unproject_window_backward(
+            _ptr(grad_cubes), _ptr(cam), _ptr(win_frame), _ptr(fa[0]), _ptr(fa[1]),
+            _ptr(fa[2]), _ptr(tl), _ptr(start), _ptr(end), _ptr(live), _ptr(clamp_mask),
+            _ptr(ghm), NW, F_, V, C, CP, H, W, int(fa[0].numel()), int(fa[1].numel()),
+            int(fa[2].numel()), VX, VY, VZ, float(heatmap_size[0]), float(heatmap_size[1]),
+            float(image_size[0]), float(image_size[1]), numerics.abi_flag(mm_mode),
+            _stream_ptr(dev))
+    _lib.check(rc, 'tempo_unproject_window_backward')
+    return ghm
+
+
 def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
                    want_grids=False, want_mask=False, out=None, mm_mode='auto',
-                   groups=None):
+                   groups=None, clamp_mask=None):
     """Root-grid unprojection on a repacked heatmap tensor.
 
     hm ``[B,V,H,W,CP]``; cam ``[B,V,32]``; axes = (ax_x, ax_y, ax_z), each
@@ -149,6 +256,17 @@ def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
         mdt = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[mask_bytes]
         mask = torch.empty(B, N, dtype=mdt, device=dev)
     groups, ng = _groups_arg(groups, B, dev)
+    if clamp_mask is not None:  # training forward: also record the clamp mask
+        _check_clamp_mask(clamp_mask, B, N, CP, dev)
+        with torch.cuda.device(dev):
+            rc = lib.tempo_unproject_root_train(
+                _ptr(hm), _ptr(cam), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), int(batched),
+                _ptr(live), _ptr(out), _ptr(grids), _ptr(mask), mask_bytes, B, V, C, CP, H,
+                W, X, Y, Z, float(heatmap_size[0]), float(heatmap_size[1]),
+                float(image_size[0]), float(image_size[1]), numerics.abi_flag(mm_mode),
+                _ptr(clamp_mask), _stream_ptr(dev))
+        _lib.check(rc, 'tempo_unproject_root_train')
+        return out, grids, mask
     with torch.cuda.device(dev):
         rc = lib.tempo_unproject_root_grouped(
             _ptr(hm), _ptr(cam), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), int(batched),
@@ -162,7 +280,7 @@ def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
 
 def unproject_window(hm, cam, fine_axes, tl, start, end, sub_cube, channels,
                      heatmap_size, image_size, win_frame=None, live=None, out=None,
-                     mm_mode='auto', groups=None):
+                     mm_mode='auto', groups=None, clamp_mask=None):
     """Per-person window unprojection.  hm ``[F,V,H,W,CP]``, cam ``[F,V,32]``,
     tl/start/end int32 ``[NW,3]``, win_frame int32 ``[NW]`` or None (NW == F).
     ``groups``: device int32 ``[NG,2]``, runs of consecutive windows with equal
@@ -200,6 +318,18 @@ def unproject_window(hm, cam, fine_axes, tl, start, end, sub_cube, channels,
         if out.numel() != NW * C * VX * VY * VZ:
             raise ValueError('out has the wrong size')
     groups, ng = _groups_arg(groups, NW, dev)
+    if clamp_mask is not None:  # training forward: also record the clamp mask
+        _check_clamp_mask(clamp_mask, NW, VX * VY * VZ, CP, dev)
+        with torch.cuda.device(dev):
+            rc = lib.tempo_unproject_window_train(
+                _ptr(hm), _ptr(cam), _ptr(win_frame), _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]),
+                _ptr(tl), _ptr(start), _ptr(end), _ptr(live), _ptr(out), NW, F_, V, C, CP, H,
+                W, int(fa[0].numel()), int(fa[1].numel()), int(fa[2].numel()), VX, VY, VZ,
+                float(heatmap_size[0]), float(heatmap_size[1]), float(image_size[0]),
+                float(image_size[1]), numerics.abi_flag(mm_mode), _ptr(clamp_mask),
+                _stream_ptr(dev))
+        _lib.check(rc, 'tempo_unproject_window_train')
+        return out
     with torch.cuda.device(dev):
         rc = lib.tempo_unproject_window_grouped(
             _ptr(hm), _ptr(cam), _ptr(win_frame), _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]),

@@ -8,9 +8,9 @@ and ``:160-388``), so ``tempo_detector.py:47,187-190`` and
 Differences, all deliberate:
 
 * HIP devices only.  There is no CPU / PyTorch fallback: CPU tensors raise.
-* Forward only.  Feature maps that require grad (training with
-  ``freeze_2d=False``) raise ``NotImplementedError`` instead of silently
-  detaching.
+* Differentiable with respect to the feature maps only (cameras, centres and
+  grids are constants, as in the reference's training): the backward pass is a
+  HIP kernel as well (``csrc``: ``unproject_backward_kernel``).
 * ``agg_method`` must be ``'mean'`` (what every config uses; the reference's
   ``'learned'`` branch is hard-wired to 5 views x 32 channels in ``ProjectLayer``
   and references undefined names in ``ProjectLayerWithMask``, ``:360-366``).
@@ -38,11 +38,79 @@ def _check_inputs(feature_maps):
     if not fm0.is_cuda:
         raise RuntimeError('tempo_amd.ProjectLayer runs on HIP devices only; got a '
                            f'{fm0.device} tensor (there is no CPU fallback)')
-    if torch.is_grad_enabled() and any(fm.requires_grad for fm in feature_maps):
-        raise NotImplementedError(
-            'tempo_amd unprojection is forward-only; run under torch.no_grad() or '
-            'detach the feature maps')
     return fm0.device
+
+
+def _wants_grad(feature_maps):
+    return torch.is_grad_enabled() and any(fm.requires_grad for fm in feature_maps)
+
+
+class _Unproject(torch.autograd.Function):
+    """Differentiable unprojection (root or window): the forward records the clamp
+    mask, the backward scatters the volume's gradient into the heatmaps
+    (``tempo_unproject_*_backward``) -- what autograd does through
+    ``project_layer.py:128-151`` / ``:278-378`` of the reference.  ``meta`` holds the
+    constant inputs (cameras, geometry); grids and the valid-view bitmap come back
+    through it, they carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, meta, *feature_maps):
+        dev = feature_maps[0].device
+        B, C, H, W = feature_maps[0].shape
+        V = len(feature_maps)
+        window = meta['kind'] == 'window'
+        items = meta['tl'].shape[0] if window else B
+        shape = meta['sub_cube'] if window else meta['cube_size']
+        n_vox = shape[0] * shape[1] * shape[2]
+        cubes = torch.empty(items, C, *shape, dtype=torch.float32, device=dev)
+        ctx.meta, ctx.masks, ctx.fm_shape, ctx.V = meta, [], (B, C, H, W), V
+        for c0, cs in _Slices(C).items:
+            hm = ops.repack_nhwc(feature_maps, c0, cs)
+            cmask = ops.new_clamp_mask(items, n_vox, hm.shape[-1], dev)
+            whole = cs == C
+            if window:
+                out = ops.unproject_window(
+                    hm, meta['cam'], meta['fine_axes'], meta['tl'], meta['start'],
+                    meta['end'], meta['sub_cube'], cs, meta['heatmap_size'],
+                    meta['image_size'], live=meta['live'], out=cubes if whole else None,
+                    mm_mode=meta['mm_mode'], clamp_mask=cmask)
+            else:
+                first = c0 == 0
+                out, g, m = ops.unproject_root(
+                    hm, meta['cam'], meta['axes'], cs, meta['heatmap_size'],
+                    meta['image_size'], live=meta['live'],
+                    want_grids=first and meta['want_grids'],
+                    want_mask=first and meta['want_mask'], out=cubes if whole else None,
+                    mm_mode=meta['mm_mode'], clamp_mask=cmask)
+                if first:
+                    meta['grids'], meta['mask'] = g, m
+            if not whole:
+                cubes[:, c0:c0 + cs] = out
+            ctx.masks.append((c0, cs, cmask, tuple(hm.shape)))
+        return cubes
+
+    @staticmethod
+    def backward(ctx, grad_cubes):
+        meta = ctx.meta
+        B, C, H, W = ctx.fm_shape
+        dev = grad_cubes.device
+        grads = [torch.zeros(B, C, H, W, dtype=torch.float32, device=dev)
+                 for _ in range(ctx.V)]
+        window = meta['kind'] == 'window'
+        for c0, cs, cmask, hm_shape in ctx.masks:
+            g = grad_cubes[:, c0:c0 + cs].float().contiguous()
+            if window:
+                ghm = ops.unproject_window_backward(
+                    g, meta['cam'], meta['fine_axes'], meta['tl'], meta['start'], meta['end'],
+                    cmask, hm_shape, meta['heatmap_size'], meta['image_size'],
+                    live=meta['live'], mm_mode=meta['mm_mode'])
+            else:
+                ghm = ops.unproject_root_backward(
+                    g, meta['cam'], meta['axes'], cmask, hm_shape, meta['heatmap_size'],
+                    meta['image_size'], live=meta['live'], mm_mode=meta['mm_mode'])
+            ops.unrepack_nchw(ghm, C, c0, cs, out=grads)
+        need = ctx.needs_input_grad[1:]
+        return (None,) + tuple(g if n else None for g, n in zip(grads, need))
 
 
 def _base_axis(size, bins):
@@ -147,6 +215,14 @@ class ProjectLayer(nn.Module):
         groups = self._share_groups(cam_host, grid_center, B)
         if groups is not None:
             groups = groups.to(device)
+        if _wants_grad(feature_maps):  # training: differentiable path
+            meta = dict(kind='root', cam=cam, axes=axes, cube_size=list(cube_size), live=live,
+                        heatmap_size=self.heatmap_size, image_size=self.image_size,
+                        mm_mode=self.mm_mode, want_grids=self.materialize_grids,
+                        want_mask=self.keep_mask)
+            cubes = _Unproject.apply(meta, *[fm.float() for fm in feature_maps])
+            self.last_mask = meta.get('mask')
+            return cubes, meta.get('grids')
         cubes = torch.empty(B, C, *cube_size, dtype=torch.float32, device=device)
         grids = mask = None
         for c0, cs in _Slices(C).items:
@@ -277,6 +353,13 @@ class ProjectLayerWithMask(nn.Module):
         cam = pack_cameras(centers, scales, cameras, self.image_size,
                            self.mm_mode).to(device)
         tl, st, en = (t.to(torch.int32).contiguous() for t in (centers_tl, start, end))
+        if _wants_grad(feature_maps):  # training: differentiable path
+            meta = dict(kind='window', cam=cam, fine_axes=self._fine_axes, tl=tl, start=st,
+                        end=en, sub_cube=list(self._sub_cube), live=live,
+                        heatmap_size=self.heatmap_size, image_size=self.image_size,
+                        mm_mode=self.mm_mode)
+            cubes = _Unproject.apply(meta, *[fm.float() for fm in feature_maps])
+            return cubes, offset
         cubes = torch.empty(B, C, *self._sub_cube, dtype=torch.float32, device=device)
         for c0, cs in _Slices(C).items:
             hm = ops.repack_nhwc(feature_maps, c0, cs)
@@ -297,6 +380,9 @@ class ProjectLayerWithMask(nn.Module):
         cubes | None)``; with ``want_cubes=False`` the ``[B,C,X,Y,Z]`` volume is never
         written to memory."""
         device = _check_inputs(feature_maps)
+        if _wants_grad(feature_maps):
+            raise NotImplementedError(
+                'get_planes is forward-only; use forward() + torch.max for training')
         B, C = feature_maps[0].shape[:2]
         if grid_center.device != device:
             grid_center = grid_center.to(device)

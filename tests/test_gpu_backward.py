@@ -1,0 +1,109 @@
+"""GPU parity of the backward pass: gradient of a seeded linear functional of the
+volume with respect to the feature maps, HIP (through the C ABI, via autograd)
+vs torch autograd through the CPU oracle.
+
+Bar: the forward's op order is reproduced bit for bit, but the backward adds
+each texel's contributions with fp32 atomics, whose order is not fixed (and
+torch's own CPU grid_sample backward accumulates sequentially), so the
+comparison is to rounding: |diff| <= 2e-5 * max(1, max|ref|), stated here."""
+import pytest
+import torch
+
+import cases
+from oracle import project_layer_ref as O
+
+pytestmark = pytest.mark.gpu
+RTOL = 2e-5
+
+
+def _grads_close(got, ref, name):
+    scale = max(1.0, float(max(r.abs().max() for r in ref)))
+    worst = max(float((g.cpu() - r).abs().max()) for g, r in zip(got, ref))
+    nz = sum(int((r != 0).sum()) for r in ref)
+    print(f'\n[{name}] grad max-abs diff {worst:.3e} (scale {scale:.3e}, {nz} non-zero entries)')
+    assert nz > 0
+    assert worst <= RTOL * scale
+    # support must agree: texels no sample touches get exactly zero
+    for g, r in zip(got, ref):
+        far = (r == 0) & (g.cpu() != 0)
+        assert int(far.sum()) == 0
+
+
+def _leafs(fms, device=None):
+    return [f.detach().clone().to(device or f.device).requires_grad_(True) for f in fms]
+
+
+@pytest.mark.parametrize('name', list(cases.ROOT_CASES))
+def test_root_backward_vs_autograd(name, gpu_device):
+    import tempo_amd
+    case = cases.build_root(name)
+    args = list(case['args'])
+    ref_fms = _leafs(args[0])
+    ref_layer = O.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, _ = ref_layer(ref_fms, *args[1:])
+    g = torch.Generator().manual_seed(7)
+    weight = torch.randn(ref_cubes.shape, generator=g)
+    (ref_cubes * weight).sum().backward()
+    ref_grads = [f.grad for f in ref_fms]
+
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    layer.keep_mask = True
+    fms = _leafs(args[0], gpu_device)
+    cubes, grids = layer(fms, *args[1:])
+    assert cubes.requires_grad and not grids.requires_grad
+    assert float((cubes.detach().cpu() - ref_cubes.detach()).abs().max()) <= 1e-5
+    (cubes * weight.to(gpu_device)).sum().backward()
+    _grads_close([f.grad for f in fms], ref_grads, name)
+    # the training forward equals the inference forward bit for bit
+    with torch.no_grad():
+        plain, _ = layer([f.detach() for f in fms], *args[1:])
+    assert torch.equal(torch.nan_to_num(plain, nan=-1.0), torch.nan_to_num(cubes.detach(), nan=-1.0))
+
+
+@pytest.mark.parametrize('name', list(cases.WINDOW_CASES))
+def test_window_backward_vs_autograd(name, gpu_device):
+    import tempo_amd
+    case = cases.build_window(name)
+    args = list(case['args'])
+    ref_fms = _leafs(args[0])
+    ref_layer = O.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, _ = ref_layer(ref_fms, *args[1:])
+    g = torch.Generator().manual_seed(8)
+    weight = torch.randn(ref_cubes.shape, generator=g)
+    (ref_cubes * weight).sum().backward()
+    ref_grads = [f.grad for f in ref_fms]
+
+    layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    fms = _leafs(args[0], gpu_device)
+    cubes, _ = layer(fms, args[1].to(gpu_device), *args[2:])
+    (cubes * weight.to(gpu_device)).sum().backward()
+    _grads_close([f.grad for f in fms], ref_grads, name)
+
+
+def test_backward_with_negative_and_saturated_values(gpu_device):
+    """Feature maps outside [0,1] exercise both sides of the clamp mask."""
+    import tempo_amd
+    case = cases.build_root('root_panoptic_noise')
+    args = list(case['args'])
+    base = [f * 3.0 - 1.0 for f in args[0]]  # values in [-1, 2)
+    ref_fms = _leafs(base)
+    ref_layer = O.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, _ = ref_layer(ref_fms, *args[1:])
+    frac_clamped = float(((ref_cubes == 0) | (ref_cubes == 1)).float().mean())
+    assert 0.05 < frac_clamped < 0.95
+    ref_cubes.sum().backward()
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    fms = _leafs(base, gpu_device)
+    cubes, _ = layer(fms, *args[1:])
+    cubes.sum().backward()
+    _grads_close([f.grad for f in fms], [f.grad for f in ref_fms], 'clamp both sides')
+
+
+def test_unrepack_inverts_repack(gpu_device):
+    from tempo_amd import ops
+    torch.manual_seed(9)
+    for (B, V, C, H, W) in ((2, 3, 15, 7, 37), (1, 2, 17, 16, 64), (2, 2, 32, 5, 13)):
+        fms = [torch.rand(B, C, H, W, device=gpu_device) for _ in range(V)]
+        back = ops.unrepack_nchw(ops.repack_nhwc(fms), C)
+        for a, b in zip(fms, back):
+            assert torch.equal(a, b)
