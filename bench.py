@@ -51,6 +51,9 @@ def parse():
     ap.add_argument('--planes', default='off', choices=['off', 'with', 'only'],
                     help='window workloads: fused axis-max planes (tempo_pose.py:172-176) '
                          'next to the volume, or instead of it')
+    ap.add_argument('--backward', action='store_true',
+                    help='also time the training step (forward with clamp mask + backward + '
+                         'un-repack) and report it beside the headline')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
 
@@ -248,7 +251,38 @@ def cpu_baseline(args):
     n = cfg['cube_size'][0] * cfg['cube_size'][1] * cfg['cube_size'][2]
     med, calls = median_call(cores, 12.0, 200)
     med1, calls1 = median_call(1, 8.0, 50)  # also at one thread
+    torch.set_num_threads(cores)
+    # the same reference-structured torch code with its tensors on the GPU (python loop over
+    # views, stock ATen kernels, F.grid_sample): what the reference's own path costs on this
+    # MI355X, forward and forward+backward -- a baseline beside the CPU one, not the product
+    gpu = {}
+    if torch.cuda.is_available():
+        dev = torch.device('cuda', torch.cuda.current_device())
+        gfms = [f.to(dev).requires_grad_(True) for f in fms]
+
+        def gcall(backward):
+            with torch.set_grad_enabled(backward):
+                cubes, _ = layer(gfms, cfg['space_size'], [cfg['space_center']],
+                                 cfg['cube_size'], centers, scales, cameras)
+                if backward:
+                    cubes.sum().backward()
+            torch.cuda.synchronize()
+
+        for backward in (False, True):
+            for _ in range(3):
+                gcall(backward)
+            ts = []
+            for _ in range(10):
+                t0 = time.perf_counter()
+                gcall(backward)
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            gpu['fwd_bwd_ms' if backward else 'fwd_ms'] = round(ts[len(ts) // 2] * 1e3, 3)
+        gpu['fwd_gsamp_s'] = round(n * V / (gpu['fwd_ms'] * 1e-3) / 1e9, 4)
+        gpu['what'] = ('oracle ProjectLayer (reference-structured torch ops) with tensors on '
+                       'this GPU, same 640000-sample call, median of 10, host-synchronised')
     return {
+        'torch_ops_on_gpu': gpu,
         'value': round(n * V / med / 1e9, 6), 'unit': 'Gsamp/s', 'cores': cores,
         'kind': 'port',
         'sample': f'oracle ProjectLayer, Panoptic cam5 root 80x80x20, B=1 (640000 samples/call), '
@@ -365,6 +399,56 @@ def main():
                    'what': 'unproject_window (volume) + torch.max over z, y, x'}
         del vol, ref_planes
 
+    # training step: forward that records the clamp mask, backward into channel-last heatmap
+    # gradients, un-repack to per-view NCHW gradients (reported beside the headline)
+    train = None
+    if rank == 0 and args.backward and args.planes == 'off':
+        ops = wl.ops
+        cp = wl.hm.shape[-1]
+        root = args.workload == 'root'
+        items = wl.B if root else wl.NW
+        cmask = ops.new_clamp_mask(items, wl.N, cp, dev)
+        gout = torch.rand(wl.out.shape, device=dev)
+        grads = [torch.zeros_like(f) for f in wl.fms]
+
+        def fwd():
+            if root:
+                ops.unproject_root(wl.hm, wl.cam, wl.axes, wl.J, wl.cfg['heatmap_size'],
+                                   wl.cfg['image_size'], out=wl.out, clamp_mask=cmask)
+            else:
+                tl, st, en = wl.geo
+                ops.unproject_window(wl.hm, wl.cam, wl.fine, tl, st, en, wl.sub, wl.J,
+                                     wl.cfg['heatmap_size'], wl.cfg['image_size'],
+                                     win_frame=wl.win_frame, out=wl.out, clamp_mask=cmask)
+
+        def bwd():
+            if root:
+                return ops.unproject_root_backward(gout, wl.cam, wl.axes, cmask, wl.hm.shape,
+                                                   wl.cfg['heatmap_size'], wl.cfg['image_size'])
+            tl, st, en = wl.geo
+            return ops.unproject_window_backward(gout, wl.cam, wl.fine, tl, st, en, cmask,
+                                                 wl.hm.shape, wl.cfg['heatmap_size'],
+                                                 wl.cfg['image_size'], win_frame=wl.win_frame)
+
+        def timed(fn, n=10):
+            for _ in range(2):
+                r = fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                r = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n, r
+
+        f_ms, _ = timed(fwd)
+        b_ms, ghm = timed(bwd)
+        u_ms, _ = timed(lambda: ops.unrepack_nchw(ghm, wl.J, out=grads))
+        train = {'forward_with_mask_ms': round(f_ms, 4), 'backward_ms': round(b_ms, 4),
+                 'unrepack_ms': round(u_ms, 4),
+                 'backward_gsamp_s': round(wl.samples / (b_ms * 1e-3) / 1e9, 3)}
+        del gout, grads, ghm, cmask
+
     if rank == 0:
         traffic, traffic_src = measured_traffic(args, wl)
         ms_step = elapsed / args.steps * 1e3
@@ -396,6 +480,8 @@ def main():
         }
         if unfused is not None:
             line['unfused_consumer'] = unfused
+        if train is not None:
+            line['training_step'] = train
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(line), flush=True)

@@ -1108,27 +1108,21 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  const bool lane_on = lane < VPS * L;
-  const int vq = lane / L;
-  const int cq = lane - vq * L;
+  // Scatter layout: CP adjacent lanes = the CP channels of one texel, so every
+  // atomic instruction adds whole 64-byte (CP = 16) texels: the L2 retires atomics
+  // line by line, and a quarter-filled line costs as much as a full one (the
+  // forward's 4-channels-per-lane layout measured 4x slower here).
+  constexpr int CPL = 4 * L;        // lanes per voxel
+  constexpr int VP2 = 64 / CPL;     // voxels per step
+  constexpr int NS2 = (kWaveVox + VP2 - 1) / VP2;
+  const bool lane_on = lane < VP2 * CPL;
+  const int vq2 = lane / CPL;
+  const int c = lane - vq2 * CPL;  // this lane's channel
   const unsigned long long* mw =
       a.cmask + ((long long)b * ((a.N + kWaveVox - 1) / kWaveVox) + (n0 >> 6)) * mask_words(L);
-  // d(volume)/d(masked view sum) per element: gradient / (count + 1e-6) where
-  // the clamp passes it, else 0
-  float gs[NSUB][4];
-#pragma unroll
-  for (int s = 0; s < NSUB; s++) {
-    const int vsl = s * VPS + vq;
-    const bool on = lane_on && vsl < kWaveVox;
-    const int rd = on ? vsl : 0;
-    const float den = s_den[rd];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const unsigned long long word = uniform_load(mw, s * 4 + j);
-      const bool pass = on && ((word >> lane) & 1ull) != 0;
-      gs[s][j] = pass ? s_g[(4 * cq + j) * TSTR + rd] / den : 0.0f;
-    }
-  }
+  // the forward's mask layout: word [s * 4 + j], bit vq * L + cq for voxel
+  // s * VPS + vq and channel 4 cq + j
+  const int cq = c >> 2, j = c & 3;
 
   const unsigned rowb = (unsigned)(a.W * CPB);
   unsigned mm = amask;
@@ -1138,13 +1132,19 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
     mm &= mm - 1;
     const int view = slot_view(a, slot);
     char* vbase = reinterpret_cast<char*>(a.ghm + (long long)frame * a.frame_stride) +
-                  (long long)view * a.view_bytes + cq * 16;
-#pragma unroll
-    for (int s = 0; s < NSUB; s++) {
-      const int vsl = s * VPS + vq;
+                  (long long)view * a.view_bytes + c * 4;
+#pragma unroll 4
+    for (int s2 = 0; s2 < NS2; s2++) {
+      const int vsl = s2 * VP2 + vq2;
       if (!(lane_on && vsl < kWaveVox)) continue;
       const GroupRec r = s_rec[slot * kWaveVox + vsl];
       if (r.flags == 0u) continue;
+      // d(volume)/d(masked view sum): gradient / (count + 1e-6) where the clamp
+      // passes it, else 0
+      const int s = vsl / VPS, vq = vsl - s * VPS;
+      const unsigned long long word = mw[s * 4 + j];
+      if (!((word >> (vq * L + cq)) & 1ull)) continue;
+      const float gs = s_g[c * TSTR + vsl] / s_den[vsl];
       const float e = 1.0f - r.w, sth = 1.0f - r.n;
       const float wt[4] = {sth * e, sth * r.w, r.n * e, r.n * r.w};
       const unsigned off[4] = {r.base, r.base + CPB, r.base + rowb, r.base + rowb + CPB};
@@ -1152,12 +1152,8 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
       for (int t = 0; t < 4; t++) {
         // column inside the map (flags) and row inside the map (byte range)
         if (!((r.flags >> (t & 1)) & 1u) || off[t] >= a.view_bytes) continue;
-        float* dst = reinterpret_cast<float*>(vbase + off[t]);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const float v = gs[s][j] * wt[t];
-          if (v != 0.0f) unsafeAtomicAdd(dst + j, v);
-        }
+        const float v = gs * wt[t];
+        if (v != 0.0f) unsafeAtomicAdd(reinterpret_cast<float*>(vbase + off[t]), v);
       }
     }
   }
