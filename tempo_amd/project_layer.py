@@ -245,6 +245,45 @@ class ProjectLayer(nn.Module):
         return self.get_voxel(feature_maps, grid_size, grid_center, cube_size,
                               centers, scales, cameras)
 
+    def forward_sequence(self, feature_maps_t, grid_size, grid_center_t, cube_size,
+                         centers_t, scales_t, cameras_t):
+        """Extension: the detector's loop over ``time_idx``
+        (``tempo_detector.py:175-191``) in one launch.  Every argument that the
+        reference indexes with ``time_idx`` is a list over T here:
+        ``feature_maps_t[t][v]`` = ``[B,C,H,W]``, ``grid_center_t[t]`` = the
+        ``[space_center]`` list of timestep t, ``centers_t[t][b][v]`` etc.  Returns
+        the cubes of ``torch.cat([forward(t) for t], dim=0)``: ``[T*B,C,X,Y,Z]``
+        (bit-identical; forward-only, grids are not materialised)."""
+        T = len(feature_maps_t)
+        device = _check_inputs(feature_maps_t[0])
+        if any(_wants_grad(f) for f in feature_maps_t):
+            raise NotImplementedError('forward_sequence is forward-only; loop over forward()')
+        B, C = feature_maps_t[0][0].shape[:2]
+        V = len(feature_maps_t[0])
+        H, W = feature_maps_t[0][0].shape[2:]
+        ax, lives = [], []
+        for t in range(T):
+            a, cs = self._axes(grid_size, grid_center_t[t], cube_size, B, device)
+            ax.append([x if x.dim() == 2 else x[None, :].expand(B, -1) for x in a])
+            lv = self._live(grid_center_t[t], B, device)
+            lives.append(torch.ones(B, dtype=torch.uint8, device=device) if lv is None else lv)
+        axes = [torch.cat([ax[t][i] for t in range(T)], 0).contiguous() for i in range(3)]
+        live = torch.cat(lives).contiguous()
+        cam = torch.cat([pack_cameras(centers_t[t], scales_t[t], cameras_t[t], self.image_size,
+                                      self.mm_mode) for t in range(T)], 0).to(device)
+        cubes = torch.empty(T * B, C, *cs, dtype=torch.float32, device=device)
+        for c0, n in _Slices(C).items:
+            cp = ops.padded_channels(n)
+            hm = torch.empty(T * B, V, H, W, cp, dtype=torch.float32, device=device)
+            for t in range(T):  # every timestep repacks straight into its slice
+                ops.repack_nhwc(feature_maps_t[t], c0, n, out=hm[t * B:(t + 1) * B])
+            out, _, _ = ops.unproject_root(hm, cam, axes, n, self.heatmap_size, self.image_size,
+                                           live=live, out=cubes if n == C else None,
+                                           mm_mode=self.mm_mode)
+            if n != C:
+                cubes[:, c0:c0 + n] = out
+        return cubes
+
 
 class ProjectLayerWithMask(nn.Module):
     """Per-person window unprojection, ``project_layer.py:160-388``."""
@@ -413,6 +452,68 @@ class ProjectLayerWithMask(nn.Module):
                 for dst, src in zip(planes, out[1:]):
                     dst[:, c0:c0 + cs] = src
         return planes[0], planes[1], planes[2], offset, cubes
+
+    def forward_sequence_planes(self, feature_maps_t, candidates, space_center, space_size,
+                                sub_space_size, sub_cube_size, centers_t, scales_t,
+                                cameras_t, want_cubes=False):
+        """Extension (SURVEY 8f rows 1 + 4): the pose regressor's two loops -- over
+        candidates (``tempo_pose.py:266``) and over ``time_idx`` (``:145-156``) -- and
+        its axis-max (``:172-176``) in one repack per timestep and ONE kernel launch.
+
+        ``feature_maps_t[t][v]`` = ``[B,C,H,W]``; ``candidates`` = ``[B,P,7]``
+        (``human_candidates[:, -1]``: the reference unprojects candidate n at every
+        timestep around its LAST-timestep centre); ``centers_t[t][b][v]`` etc.
+        Returns ``(plane_xy, plane_xz, plane_yz)`` each ``[B,P,T,C,64,64]`` =
+        ``torch.max`` over z / y / x of what ``forward(feature_maps_t[t],
+        candidates[:, n], ...)`` returns, ``offset [B,P,3]``, and the cubes
+        ``[B,P,T,C,X,Y,Z]`` when ``want_cubes`` (else None: never written)."""
+        T = len(feature_maps_t)
+        device = _check_inputs(feature_maps_t[0])
+        if any(_wants_grad(f) for f in feature_maps_t):
+            raise NotImplementedError('forward_sequence_planes is forward-only')
+        self.set_space_size(space_center, space_size, sub_space_size, sub_cube_size, device)
+        B, C = feature_maps_t[0][0].shape[:2]
+        V = len(feature_maps_t[0])
+        H, W = feature_maps_t[0][0].shape[2:]
+        P = candidates.shape[1]
+        cand = candidates.to(device).reshape(B * P, -1)
+        centers_tl, offset, start, end = self.window_geometry(cand)
+        self._ensure_grids(device)
+        live = None
+        if cand.shape[1] != 3:
+            live = (cand[:, 3] >= 0).to(torch.uint8).repeat_interleave(T).contiguous()
+        # windows ordered (b, p, t); frames ordered (t, b)
+        rep = lambda x: x.to(torch.int32).repeat_interleave(T, 0).contiguous()
+        tl, st, en = rep(centers_tl), rep(start), rep(end)
+        i = torch.arange(B * P * T, device=device)
+        win_frame = ((i % T) * B + i // (P * T)).to(torch.int32).contiguous()
+        cam = torch.cat([pack_cameras(centers_t[t], scales_t[t], cameras_t[t], self.image_size,
+                                      self.mm_mode) for t in range(T)], 0).to(device)
+        vx, vy, vz = self._sub_cube
+        NW = B * P * T
+        cubes = (torch.empty(NW, C, vx, vy, vz, dtype=torch.float32, device=device)
+                 if want_cubes else None)
+        planes = [torch.empty(NW, C, *sh, dtype=torch.float32, device=device)
+                  for sh in ((vx, vy), (vx, vz), (vy, vz))]
+        for c0, n in _Slices(C).items:
+            cp = ops.padded_channels(n)
+            hm = torch.empty(T * B, V, H, W, cp, dtype=torch.float32, device=device)
+            for t in range(T):
+                ops.repack_nhwc(feature_maps_t[t], c0, n, out=hm[t * B:(t + 1) * B])
+            whole = n == C
+            out = ops.unproject_window_planes(
+                hm, cam, self._fine_axes, tl, st, en, self._sub_cube, n, self.heatmap_size,
+                self.image_size, win_frame=win_frame, live=live, want_cubes=want_cubes,
+                mm_mode=self.mm_mode, out=cubes if whole else None,
+                planes_out=planes if whole else None)
+            if not whole:
+                if want_cubes:
+                    cubes[:, c0:c0 + n] = out[0]
+                for dst, src in zip(planes, out[1:]):
+                    dst[:, c0:c0 + n] = src
+        shape = lambda x: x.view(B, P, T, *x.shape[1:])
+        return (shape(planes[0]), shape(planes[1]), shape(planes[2]), offset.view(B, P, 3),
+                None if cubes is None else shape(cubes))
 
     def forward(self, feature_maps, grid_center, space_center, space_size,
                 sub_space_size, sub_cube_size, centers, scales, cameras):

@@ -262,3 +262,55 @@ def test_window_planes_equal_axis_max(name, want_cubes, gpu_device):
     ref_cubes, _ = ref_layer(*case['args'])
     for got, ref in zip((pxy, pxz, pyz), _planes_ref(ref_cubes)):
         assert float((got.cpu() - ref).abs().max()) <= TOL
+
+
+def test_root_forward_sequence_equals_loop(gpu_device):
+    """tempo_detector.py:175-191: the loop over time_idx in one launch."""
+    import tempo_amd
+    T = 3
+    cs = [cases.build_root('root_panoptic_small', full=dict(cases.ROOT_CASES['root_panoptic_small'],
+                                                            seed=50 + t)) for t in range(T)]
+    ds = [cases.to_device(c, gpu_device) for c in cs]
+    layer = tempo_amd.ProjectLayer(cs[0]['image_size'], cs[0]['heatmap_size'], 'mean')
+    with torch.no_grad():
+        loop = torch.cat([layer(*d['args'])[0] for d in ds], dim=0)
+        seq = layer.forward_sequence([d['args'][0] for d in ds], ds[0]['args'][1],
+                                     [d['args'][2] for d in ds], ds[0]['args'][3],
+                                     [d['args'][4] for d in ds], [d['args'][5] for d in ds],
+                                     [d['args'][6] for d in ds])
+    canon = lambda t: torch.nan_to_num(t, nan=-1.0)
+    assert seq.shape == loop.shape and torch.equal(canon(seq), canon(loop))
+
+
+def test_window_forward_sequence_planes_equals_loops(gpu_device):
+    """tempo_pose.py:145-176 + :266: candidates x timesteps x axis-max in one launch."""
+    import tempo_amd
+    from tempo_amd import synthetic as S
+    cfg = S.PANOPTIC
+    T, B, P = 2, 2, 3
+    space, sub, sub_cube = [2000, 2000, 2000], [1000, 1000, 1000], [16, 16, 16]
+    cams = [S.ring_cameras(5, seed=60 + b, target=cfg['space_center']) for b in range(B)]
+    w, h = cfg['heatmap_size']
+    fms_t = [[f.to(gpu_device) for f in S.make_heatmaps(B, 5, cfg['num_joints'], h, w,
+                                                        kind='noise', seed=70 + t)]
+             for t in range(T)]
+    metas = [S.frame_meta(cams[b], 1, cfg['raw_size'], cfg['image_size']) for b in range(B)]
+    centers = [m[0][0] for m in metas]
+    scales = [m[1][0] for m in metas]
+    cameras = [m[2][0] for m in metas]
+    cand = S.make_proposals(B * P, cfg['space_center'], space, seed=61, invalid_every=4,
+                            margin=0.0).view(B, P, 7).to(gpu_device)
+    layer = tempo_amd.ProjectLayerWithMask(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    with torch.no_grad():
+        pxy, pxz, pyz, off, cubes = layer.forward_sequence_planes(
+            fms_t, cand, cfg['space_center'], space, sub, sub_cube, [centers] * T,
+            [scales] * T, [cameras] * T, want_cubes=True)
+        for n in range(P):
+            for t in range(T):
+                ref, ref_off = layer(fms_t[t], cand[:, n], cfg['space_center'], space, sub,
+                                     sub_cube, centers, scales, cameras)
+                assert torch.equal(cubes[:, n, t], ref)
+                assert torch.equal(off[:, n], ref_off)
+                assert torch.equal(pxy[:, n, t], ref.max(dim=4)[0])
+                assert torch.equal(pxz[:, n, t], ref.max(dim=3)[0])
+                assert torch.equal(pyz[:, n, t], ref.max(dim=2)[0])
