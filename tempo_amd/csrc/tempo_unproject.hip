@@ -1041,7 +1041,6 @@ constexpr int backward_wave_lds(int V, int L) {
 template <int MODE, int L, int UNF>
 __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const UnprojArgs a) {
   constexpr int VPS = 64 / L;
-  constexpr int NSUB = (kWaveVox + VPS - 1) / VPS;
   constexpr int CPB = L * 16;
   constexpr int TSTR = kWaveVox + 1;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1415,6 +1414,11 @@ int check_common(int V, int C, int CP, int H, int W) {
   return TEMPO_OK;
 }
 
+// the backward keeps one footprint record per view and voxel of a tile in LDS
+bool backward_fits(int V, int CP) {
+  return (kThreads / 64) * (V * kWaveVox * 16 + kWaveVox * 4 + CP * (kWaveVox + 1) * 4) <= 65536;
+}
+
 struct Extra {
   unsigned long long* cmask = nullptr;  // forward: record / backward: read the clamp mask
   float* ghm = nullptr;                 // backward: gradient of the heatmaps (accumulated)
@@ -1631,6 +1635,8 @@ int root_impl(const float* hm, const float* cam, const float* ax_x, const float*
   if (mask && !((mask_bytes == 1 && V <= 8) || (mask_bytes == 2 && V <= 16) ||
                 mask_bytes == 4))
     return TEMPO_E_ARG;
+  if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
+  if (ex.ghm != nullptr && !backward_fits(V, CP)) return TEMPO_E_DIM;
   UnprojArgs a = {};
   a.hm = hm; a.cam = cam;
   a.ax[0] = ax_x; a.ax[1] = ax_y; a.ax[2] = ax_z;
@@ -1724,6 +1730,8 @@ int window_impl(const float* hm, const float* cam, const int32_t* win_frame, con
   if (win_frame == nullptr && NW != F) return TEMPO_E_ARG;
   const long long N = (long long)VX * VY * VZ;
   if (N * 4 >= 0x80000000LL) return TEMPO_E_SIZE;
+  if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
+  if (ex.ghm != nullptr && !backward_fits(V, CP)) return TEMPO_E_DIM;
   UnprojArgs a = {};
   a.hm = hm; a.cam = cam;
   a.ax[0] = fx; a.ax[1] = fy; a.ax[2] = fz;

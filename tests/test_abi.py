@@ -68,3 +68,41 @@ def test_bad_arguments_are_rejected_before_any_launch():
     assert lib.tempo_repack_nhwc(ptrs, 2, 1, 15, 0, 15, 8, 8, 16, None, None) == -1
     assert lib.tempo_repack_nhwc(ptrs, 2, 1, 15, 4, 15, 8, 8, 16, one, None) == -2
     assert lib.tempo_project_points(one, one, 0, 5, 1., 1., 1., 1., 0, one, one, one, None) == -2
+
+
+def test_new_entry_points_reject_bad_arguments():
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    one = P(16)
+    planes = lambda **kw: lib.tempo_unproject_window_planes(
+        one, one, None, one, one, one, one, one, one, None, kw.get('cubes', None),
+        kw.get('xy', one), None, None, kw.get('NW', 4), 4, 5, 15, kw.get('CP', 16), 128, 240, 253,
+        253, 64, 64, 64, 64, 240.0, 128.0, 960.0, 512.0, kw.get('mm', 0), None)
+    assert planes(xy=None) == -1            # no output at all
+    assert planes(NW=0) == -2 and planes(CP=18) == -3 and planes(mm=3) == -5
+    grouped = lambda **kw: lib.tempo_unproject_root_grouped(
+        one, one, one, one, one, 0, None, one, None, None, 0, 4, 5, 15, 16, 128, 240, 80, 80, 20,
+        240.0, 128.0, 960.0, 512.0, 0, kw.get('groups', one), kw.get('ng', 2), None)
+    assert grouped(groups=None, ng=2) == -5 and grouped(ng=0) == -5 and grouped(ng=5) == -5
+    train = lambda **kw: lib.tempo_unproject_root_train(
+        one, one, one, one, one, 0, None, one, None, None, 0, 1, 5, 15, 16, 128, 240, 80, 80, 20,
+        240.0, 128.0, 960.0, 512.0, 0, kw.get('cmask', one), None)
+    assert train(cmask=None) == -1
+    bwd = lambda **kw: lib.tempo_unproject_root_backward(
+        kw.get('g', one), one, one, one, one, 0, None, kw.get('cmask', one), kw.get('ghm', one),
+        1, kw.get('V', 5), 15, 16, 128, 240, 80, 80, 20, 240.0, 128.0, 960.0, 512.0,
+        kw.get('mm', 0), None)
+    assert bwd(g=None) == -1 and bwd(cmask=None) == -1 and bwd(ghm=None) == -1
+    assert bwd(mm=1) == -5
+    assert bwd(V=13) == -2                  # footprint records of 13 views exceed the LDS budget
+    wbwd = lambda **kw: lib.tempo_unproject_window_backward(
+        one, one, None, one, one, one, one, one, one, None, one, kw.get('ghm', one),
+        kw.get('NW', 4), 4, 5, 15, 16, 128, 240, 253, 253, 64, 64, 64, 64, 240.0, 128.0, 960.0,
+        512.0, 0, None)
+    assert wbwd(ghm=None) == -1 and wbwd(NW=8) == -5
+    assert lib.tempo_clamp_mask_words(128000, 16) == 2000 * 16
+    assert lib.tempo_clamp_mask_words(65, 20) == 2 * 24
+    assert lib.tempo_clamp_mask_words(0, 16) == -2 and lib.tempo_clamp_mask_words(64, 18) == -3
+    ptrs = (ctypes.c_void_p * 2)(16, 16)
+    assert lib.tempo_unrepack_nchw(None, ptrs, 2, 1, 15, 0, 15, 8, 8, 16, None) == -1
+    assert lib.tempo_unrepack_nchw(one, ptrs, 2, 1, 15, 4, 15, 8, 8, 16, None) == -2
