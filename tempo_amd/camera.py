@@ -126,36 +126,123 @@ def _camera_record(param, out, mm_mode='auto'):
         out[CAM_HASD] = 1.0
 
 
+# Packed record fields [0:24] per distinct camera CONTENT, across calls: the
+# reference's datasets hand a fresh dict per sample and view, but a recording has
+# only V distinct calibrations.  Key = the raw bytes of the float32 fields.
+_RECORDS = {}
+_RECORDS_MAX = 4096
+
+
+def _content_key(param, mm_mode):
+    if 'intrinsics' in param:
+        raise NotImplementedError(
+            "camera dicts with 'intrinsics' (FisheyeCameraTorch) are not supported")
+    f32 = np.float32
+    parts = [np.asarray(param['R'], dtype=f32).tobytes(), b'|',
+             np.asarray(param['T'], dtype=f32).tobytes(), b'|']
+    if 'K' in param:
+        parts += [b'K', np.asarray(param['K'], dtype=f32).tobytes()]
+    elif 'f' in param and 'c' in param:
+        parts += [b'f', np.asarray(param['f'], dtype=f32).tobytes(),
+                  np.asarray(param['c'], dtype=f32).tobytes()]
+    if 'k' in param and 'p' in param:
+        parts += [b'd', np.asarray(param['k'], dtype=f32).tobytes(), b'|',
+                  np.asarray(param['p'], dtype=f32).tobytes()]
+    mode = mm_mode if isinstance(mm_mode, (str, type(None))) else tuple(sorted(mm_mode.items()))
+    return (b''.join(parts), mode)
+
+
+def _bulk_keys(params, mm_mode):
+    """Content keys of many camera dicts with one array conversion per field
+    (per-dict conversions dominate the packing time otherwise).  None when the
+    dicts do not share one format or a field is malformed: the per-dict path then
+    validates and reports."""
+    first = params[0]
+    fields = ['R', 'T']
+    if 'K' in first:
+        fields.append('K')
+    elif 'f' in first and 'c' in first:
+        fields += ['f', 'c']
+    else:
+        return None
+    dist = 'k' in first and 'p' in first
+    if dist:
+        fields += ['k', 'p']
+    try:
+        for q in params:
+            if 'intrinsics' in q or ('K' in q) != ('K' in first) or \
+                    (('k' in q and 'p' in q) != dist):
+                return None
+        cols = [np.asarray([q[f] for q in params], dtype=np.float32).reshape(len(params), -1)
+                for f in fields]
+    except (KeyError, ValueError, TypeError):
+        return None
+    if cols[0].shape[1] != 9 or cols[1].shape[1] != 3:
+        return None
+    blob = np.ascontiguousarray(np.concatenate(cols, axis=1))
+    mode = mm_mode if isinstance(mm_mode, (str, type(None))) else tuple(sorted(mm_mode.items()))
+    tag = ('bulk', tuple(fields), tuple(c.shape[1] for c in cols), mode)
+    return [(blob[i].tobytes(), tag) for i in range(len(params))]
+
+
+def _record_for(param, mm_mode):
+    """``out[0:24]`` of :func:`_camera_record`, memoised by content."""
+    key = _content_key(param, mm_mode)
+    rec = _RECORDS.get(key)
+    if rec is None:
+        rec = torch.zeros(CAM_TRANS, dtype=torch.float32)
+        _camera_record(param, rec, mm_mode)
+        if len(_RECORDS) >= _RECORDS_MAX:
+            _RECORDS.clear()
+        _RECORDS[key] = rec
+    return rec
+
+
 def pack_cameras(centers, scales, cameras, image_size, mm_mode='auto'):
     """``centers[b][v]``, ``scales[b][v]`` (np.float32 (2,)), ``cameras[b][v]``
     (dict) -> CPU fp32 tensor ``[B,V,32]``.  ``mm_mode``: rounding flavour used
     for ``T_w2c = -(T^T @ R)``, see ``tempo_amd.numerics`` (default: the torch
-    op itself, i.e. as the reference on this host)."""
+    op itself, i.e. as the reference on this host).  ``cameras`` may also be a
+    table this function returned earlier (any device): it is passed through, so
+    a caller can pack the calibration of a sequence once."""
+    if isinstance(cameras, torch.Tensor):
+        # already packed (a caller that keeps the table of its sequence): pass through
+        if cameras.dim() != 3 or cameras.shape[-1] != CAM_FLOATS or cameras.dtype != torch.float32:
+            raise ValueError('a packed camera table must be fp32 [B,V,32]')
+        return cameras
     B = len(cameras)
     V = len(cameras[0])
-    table = torch.zeros(B, V, CAM_FLOATS, dtype=torch.float32)
-    cen = np.zeros((B * V, 2), dtype=np.float32)
-    scl = np.zeros((B * V, 2), dtype=np.float32)
-    seen = {}
     for b in range(B):
         if len(cameras[b]) != V or len(centers[b]) != V or len(scales[b]) != V:
             raise ValueError('every batch item needs one center/scale/camera per view')
-        for v in range(V):
-            cen[b * V + v] = centers[b][v]
-            scl[b * V + v] = np.asarray(scales[b][v], dtype=np.float32) / 200.0
-            param = cameras[b][v]
-            hit = seen.get(id(param))
-            if hit is None:
-                _camera_record(param, table[b, v], mm_mode)
-                seen[id(param)] = (b, v)
+    table = torch.zeros(B, V, CAM_FLOATS, dtype=torch.float32)
+    flat = table.view(B * V, CAM_FLOATS)
+    params = [cameras[b][v] for b in range(B) for v in range(V)]
+    keys = _bulk_keys(params, mm_mode)
+    seen = {}
+    rows = []
+    for i, param in enumerate(params):
+        rec = seen.get(id(param))
+        if rec is None:
+            if keys is None:
+                rec = _record_for(param, mm_mode)
             else:
-                table[b, v, :CAM_TRANS] = table[hit[0], hit[1], :CAM_TRANS]
+                rec = _RECORDS.get(keys[i])
+                if rec is None:
+                    rec = _record_for(param, mm_mode)  # validates, fills, memoises
+                    _RECORDS[keys[i]] = rec
+            seen[id(param)] = rec
+        rows.append(rec)
+    flat[:, :CAM_TRANS] = torch.stack(rows)
+    cen = np.asarray([centers[b][v] for b in range(B) for v in range(V)],
+                     dtype=np.float32).reshape(B * V, 2)
+    scl = np.asarray([scales[b][v] for b in range(B) for v in range(V)],
+                     dtype=np.float32).reshape(B * V, 2) / np.float32(200.0)
     # identical (center, scale) pairs share one solve
     key = np.concatenate([cen, scl], axis=1)
     uniq, inv = np.unique(key, axis=0, return_inverse=True)
     trans = affine_transforms(uniq[:, :2], uniq[:, 2:], image_size)
     trans32 = torch.as_tensor(trans, dtype=torch.float).reshape(-1, 6)
-    flat = table.view(B * V, CAM_FLOATS)
     flat[:, CAM_TRANS:CAM_TRANS + 6] = trans32[torch.as_tensor(inv.reshape(-1))]
     wh = torch.from_numpy(cen * 2)  # width, height = center * 2 (float32)
     flat[:, CAM_WIDTH] = wh[:, 0]

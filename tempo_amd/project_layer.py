@@ -140,6 +140,7 @@ class ProjectLayer(nn.Module):
         self.last_mask = None  # valid-view bitmap of the last call when keep_mask
         self.keep_mask = False
         self.materialize_grids = True  # the reference's 2nd return; callers drop it
+        self._axes_cache = {}
         # batch items with bit-identical camera records and grid centre (frames of
         # one recording) share one projection per voxel; results do not change
         # (opt-in: on MI355X the root kernel is bound by the texel gather, not by the
@@ -158,10 +159,21 @@ class ProjectLayer(nn.Module):
     def _axes(self, grid_size, grid_center, cube_size, B, device):
         grid_size = _triple(grid_size, (int, float))
         cube_size = _triple(cube_size, int)
-        base = [_base_axis(grid_size[i], cube_size[i]) for i in range(3)]
         if len(grid_center) == 1:
+            # one shared centre (the detector's call): the three axis vectors depend on
+            # a handful of numbers, keep them on the device between calls
             gc = grid_center[0]
-            return [(base[i] + float(gc[i])).to(device) for i in range(3)], cube_size
+            key = (tuple(float(v) for v in grid_size), tuple(float(gc[i]) for i in range(3)),
+                   tuple(cube_size), str(device))
+            hit = self._axes_cache.get(key)
+            if hit is None:
+                hit = [(_base_axis(grid_size[i], cube_size[i]) + float(gc[i])).to(device)
+                       for i in range(3)]
+                if len(self._axes_cache) >= 32:
+                    self._axes_cache.clear()
+                self._axes_cache[key] = hit
+            return list(hit), list(cube_size)
+        base = [_base_axis(grid_size[i], cube_size[i]) for i in range(3)]
         if isinstance(grid_center, torch.Tensor):
             gc = grid_center[:, :3].to(device=device, dtype=torch.float32)
         else:
@@ -184,7 +196,7 @@ class ProjectLayer(nn.Module):
     def _share_groups(self, cam_host, grid_center, B):
         """Runs of consecutive batch items whose packed camera records and grid
         centre are bit-identical (host-side comparison, no device sync)."""
-        if not self.share_projection or B < 2:
+        if not self.share_projection or B < 2 or cam_host.is_cuda:
             return None
         if len(grid_center) == 1:
             extra = None

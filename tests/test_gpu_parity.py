@@ -314,3 +314,17 @@ def test_window_forward_sequence_planes_equals_loops(gpu_device):
                 assert torch.equal(pxy[:, n, t], ref.max(dim=4)[0])
                 assert torch.equal(pxz[:, n, t], ref.max(dim=3)[0])
                 assert torch.equal(pyz[:, n, t], ref.max(dim=2)[0])
+
+
+def test_prepacked_camera_table_is_accepted(gpu_device):
+    """A caller may pack the calibration of its sequence once and hand the table over."""
+    import tempo_amd
+    from tempo_amd.camera import pack_cameras
+    case = cases.to_device(cases.build_root('root_panoptic_small'), gpu_device)
+    args = list(case['args'])
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    with torch.no_grad():
+        ref, _ = layer(*args)
+        table = pack_cameras(args[4], args[5], args[6], case['image_size']).to(gpu_device)
+        got, _ = layer(*args[:4], None, None, table)
+    assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(ref, nan=-1.0))
