@@ -107,3 +107,53 @@ def test_unrepack_inverts_repack(gpu_device):
         back = ops.unrepack_nchw(ops.repack_nhwc(fms), C)
         for a, b in zip(fms, back):
             assert torch.equal(a, b)
+
+
+def test_backward_full_root_grid_config1(gpu_device):
+    """BASELINE configs[0] size: one Panoptic frame, 80x80x20 grid, every texel's gradient."""
+    import tempo_amd
+    spec = dict(cfg='panoptic', B=1, cube=[80, 80, 20], hm='noise', seed=401)
+    case = cases.build_root(None, full=spec)
+    args = list(case['args'])
+    ref_fms = _leafs(args[0])
+    ref_layer = O.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, _ = ref_layer(ref_fms, *args[1:])
+    g = torch.Generator().manual_seed(9)
+    weight = torch.randn(ref_cubes.shape, generator=g)
+    (ref_cubes * weight).sum().backward()
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    fms = _leafs(args[0], gpu_device)
+    cubes, _ = layer(fms, *args[1:])
+    (cubes * weight.to(gpu_device)).sum().backward()
+    _grads_close([f.grad for f in fms], [f.grad for f in ref_fms], 'config 1 backward')
+
+
+def test_backward_is_linear_and_matches_directional_derivative(gpu_device):
+    """Size-independent properties at the batch-8 root size: the backward is linear in the
+    incoming gradient, and <grad, d> equals the change of the (clamp-free) volume along d."""
+    import tempo_amd
+    spec = dict(cfg='panoptic', B=8, cube=[80, 80, 20], hm='noise', seed=402)
+    case = cases.to_device(cases.build_root(None, full=spec), gpu_device)
+    args = list(case['args'])
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    layer.materialize_grids = False
+    base = [f * 0.5 + 0.25 for f in args[0]]  # volume stays inside (0, 1): no clamping
+    fms = _leafs(base)
+    cubes, _ = layer(fms, *args[1:])
+    g = torch.Generator(device=gpu_device).manual_seed(10)
+    w1 = torch.randn(cubes.shape, device=gpu_device, generator=g)
+    w2 = torch.randn(cubes.shape, device=gpu_device, generator=g)
+    g1 = torch.autograd.grad((cubes * w1).sum(), fms, retain_graph=True)
+    g2 = torch.autograd.grad((cubes * w2).sum(), fms, retain_graph=True)
+    g12 = torch.autograd.grad((cubes * (w1 + 2 * w2)).sum(), fms)
+    for a, b, c in zip(g1, g2, g12):
+        assert float((a + 2 * b - c).abs().max()) <= 1e-4 * max(1.0, float(c.abs().max()))
+    # the volume is linear in the maps where nothing clamps: f(x + d) - f(x) = J d exactly
+    d = [torch.randn(f.shape, device=gpu_device, generator=g) * 0.01 for f in fms]
+    with torch.no_grad():
+        plus, _ = layer([f + e for f, e in zip(base, d)], *args[1:])
+        here, _ = layer(base, *args[1:])
+    finite = torch.isfinite(plus) & torch.isfinite(here)
+    lhs = float(((plus - here) * w1)[finite].sum())
+    rhs = float(sum((a * e).sum() for a, e in zip(g1, d)))
+    assert abs(lhs - rhs) <= 2e-3 * max(1.0, abs(rhs))

@@ -328,3 +328,46 @@ def test_prepacked_camera_table_is_accepted(gpu_device):
         table = pack_cameras(args[4], args[5], args[6], case['image_size']).to(gpu_device)
         got, _ = layer(*args[:4], None, None, table)
     assert torch.equal(torch.nan_to_num(got, nan=-1.0), torch.nan_to_num(ref, nan=-1.0))
+
+
+@pytest.mark.parametrize('dims', [(6, 8, 64), (8, 6, 64), (10, 12, 64), (5, 4, 32), (3, 7, 20)])
+def test_planes_kernel_dispatch_edges(dims, gpu_device):
+    """Window shapes on both sides of the fused-planes kernel's conditions (64-voxel
+    columns, VY a multiple of 4; x walks of 8 with a ragged end) against torch.max of the
+    volume the plain kernel writes; windows partly outside the lattice, one skipped."""
+    from tempo_amd import ops, synthetic as S
+    from tempo_amd.camera import pack_cameras
+    cfg = S.PANOPTIC
+    cams = S.ring_cameras(5, seed=81, target=cfg['space_center'])
+    F, NW, J = 2, 5, cfg['num_joints']
+    w, h = cfg['heatmap_size']
+    fms = [f.to(gpu_device) for f in S.make_heatmaps(F, 5, J, h, w, kind='noise', seed=82)]
+    centers, scales, cameras = S.frame_meta(cams, F, cfg['raw_size'], cfg['image_size'])
+    cam = pack_cameras(centers, scales, cameras, cfg['image_size']).to(gpu_device)
+    hm = ops.repack_nhwc(fms)
+    fine = [torch.linspace(-1500, 1500, 97) + c for c in cfg['space_center']]
+    fine = [a.to(gpu_device) for a in fine]
+    g = torch.Generator().manual_seed(83)
+    tl = torch.randint(-10, 80, (NW, 3), generator=g, dtype=torch.int32)
+    vox = torch.tensor(dims, dtype=torch.int32)
+    lim = torch.tensor([97, 97, 97], dtype=torch.int32)
+    start = torch.maximum(tl + torch.randint(0, 3, (NW, 3), generator=g, dtype=torch.int32),
+                          torch.zeros_like(tl))
+    end = torch.maximum(torch.minimum(tl + vox - torch.randint(0, 3, (NW, 3), generator=g,
+                                                               dtype=torch.int32), lim), start + 1)
+    dev = lambda t: t.contiguous().to(gpu_device)
+    win_frame = dev(torch.tensor([0, 1, 1, 0, 1], dtype=torch.int32))
+    live = dev(torch.tensor([1, 1, 0, 1, 1], dtype=torch.uint8))
+    args = (hm, cam, fine, dev(tl), dev(start), dev(end), list(dims), J, cfg['heatmap_size'],
+            cfg['image_size'])
+    vol = ops.unproject_window(*args, win_frame=win_frame, live=live)
+    cubes, pxy, pxz, pyz = ops.unproject_window_planes(*args, win_frame=win_frame, live=live,
+                                                       want_cubes=True)
+    _, qxy, qxz, qyz = ops.unproject_window_planes(*args, win_frame=win_frame, live=live)
+    torch.cuda.synchronize()
+    canon = lambda t: torch.nan_to_num(t, nan=-1.0)
+    assert float(vol[2].abs().max()) == 0.0 and float(vol.abs().max()) > 0.0
+    assert torch.equal(canon(cubes), canon(vol))
+    for p, q, dim in ((pxy, qxy, 4), (pxz, qxz, 3), (pyz, qyz, 2)):
+        ref = vol.max(dim=dim)[0]
+        assert torch.equal(canon(p), canon(ref)) and torch.equal(canon(q), canon(ref))
