@@ -35,7 +35,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--workload', default='root', choices=['root', 'window', 'window_h36m'])
+    ap.add_argument('--workload', default='root',
+                    choices=['root', 'window', 'window_h36m', 'dense'])
     ap.add_argument('--timesteps', type=int, default=None,
                     help='window workloads: frames per sequence; the T windows of one proposal '
                          'share geometry and calibration (default 1; window_h36m: 4)')
@@ -212,11 +213,61 @@ class WindowH36MWorkload(WindowWorkload):
     default_T = 4
 
 
+class DenseWorkload:
+    """BASELINE configs[4]: one frame, 10 views, 15 joints, one 128^3 grid.  With N ranks the
+    grid is z-slab-sharded (rank r computes planes [r*128/N, (r+1)*128/N) from replicated
+    heatmaps) and ONE all-gather over RCCL/xGMI plus a device permute reassembles it: the total
+    work is fixed, so this workload reports strong scaling."""
+    name = 'dense_128cubed_10views_zslab'
+    scaling = 'strong'
+
+    def __init__(self, args, dev, seed):
+        import copy
+        from tempo_amd import ops, parallel, project_layer as PL, synthetic as S
+        self.ops, self.parallel = ops, parallel
+        cfg = copy.deepcopy(S.PANOPTIC)
+        cfg['num_views'], cfg['cube_size'] = 10, [128, 128, 128]
+        args = copy.copy(args)
+        args.batch, args.calibrations = 1, 1
+        # every rank holds the same frame (replicated heatmaps): same seed on all ranks
+        self.cfg, self.fms, self.cam, _ = make_inputs(args, dev, 0, cfg)
+        self.B, self.V, self.J = 1, 10, cfg['num_joints']
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        rank = int(os.environ.get('RANK', '0'))
+        X, Y, Z = cfg['cube_size']
+        z0, z1 = parallel.zslab_range(Z, rank, self.world)
+        self.axes = [(PL._base_axis(cfg['space_size'][i], cfg['cube_size'][i]) +
+                      cfg['space_center'][i]).to(dev) for i in range(3)]
+        self.axes[2] = self.axes[2][z0:z1].contiguous()
+        self.N = X * Y * (z1 - z0)
+        w, h = cfg['heatmap_size']
+        self.hm = torch.empty(1, self.V, h, w, ops.padded_channels(self.J), device=dev)
+        self.out = torch.empty(1, self.J, X, Y, z1 - z0, device=dev)
+        self.full = None
+        self.samples = self.N * self.V  # per rank; the bench multiplies by the world size
+        self.kernel_bytes = 4 * self.J * self.N + 4 * self.V * self.J * h * w + 128 * self.V
+        self.kernel_name = 'unproject_kernel<ROOT>'
+        self.groups = None
+
+    def repack(self):
+        self.ops.repack_nhwc(self.fms, out=self.hm)
+
+    def kernel(self):
+        self.ops.unproject_root(self.hm, self.cam, self.axes, self.J, self.cfg['heatmap_size'],
+                                self.cfg['image_size'], out=self.out)
+
+    def step(self):
+        self.repack()
+        self.kernel()
+        if self.world > 1:
+            self.full = self.parallel.gather_z_slabs(self.out)
+
+
 def make_workload(args, dev, seed):
     if args.workload == 'window_h36m' and args.proposals == 10:
         args.proposals = 1  # one person per sequence
-    return {'root': RootWorkload, 'window': WindowWorkload,
-            'window_h36m': WindowH36MWorkload}[args.workload](args, dev, seed)
+    return {'root': RootWorkload, 'window': WindowWorkload, 'window_h36m': WindowH36MWorkload,
+            'dense': DenseWorkload}[args.workload](args, dev, seed)
 
 
 def cpu_baseline(args):
@@ -301,7 +352,8 @@ def measured_traffic(args, wl):
     64 B per fabric request; this kernel's texel fetches are 64-byte requests, so it is taken at
     face value (calibration: profiles/r01/fetch_size_calibration.txt)."""
     import csv
-    if (args.workload == 'window_h36m' or (args.timesteps or 1) != 1 or args.calibrations != 1
+    if (args.workload in ('window_h36m', 'dense') or (args.timesteps or 1) != 1
+            or args.calibrations != 1
             or args.planes == 'with' or args.share):
         return None, None
     tag = 'root' if args.workload == 'root' else ('planes' if args.planes == 'only' else 'window')
@@ -459,16 +511,19 @@ def main():
             'unit': 'Gsamp/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_step, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': getattr(wl, 'scaling', 'weak'),
+            'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': wl.name, 'frames_per_gpu': args.batch,
+            'config': {'workload': wl.name, 'frames_per_gpu': wl.B,
                        'calibrations_per_batch': max(1, min(args.calibrations, args.batch)),
                        'shared_projection': getattr(wl, 'groups', None) is not None,
                        'timesteps': getattr(wl, 'T', 1),
                        'planes': getattr(wl, 'planes_mode', 'off'),
                        'views': wl.V,
                        'joints': wl.J, 'samples_per_step_per_gpu': wl.samples,
-                       'partition': f'frames x proposals over {world} rank(s), no collective'},
+                       'partition': (f'z-slabs over {world} rank(s), one all-gather'
+                                     if args.workload == 'dense' else
+                                     f'frames x proposals over {world} rank(s), no collective')},
             'roofline': {
                 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
