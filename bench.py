@@ -55,6 +55,9 @@ def parse():
     ap.add_argument('--backward', action='store_true',
                     help='also time the training step (forward with clamp mask + backward + '
                          'un-repack) and report it beside the headline')
+    ap.add_argument('--chunk', type=int, default=8,
+                    help='root workload: frames per repack+unproject chunk (one reused '
+                         'channel-last buffer that stays in the Infinity Cache)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
 
@@ -103,7 +106,10 @@ class RootWorkload:
         self.N = X * Y * Z
         w, h = cfg['heatmap_size']
         cp = ops.padded_channels(self.J)
-        self.hm = torch.empty(self.B, self.V, h, w, cp, device=dev)
+        # frames go through in chunks that reuse one channel-last buffer (ops.root_step);
+        # the grouped launch works on the whole batch
+        self.chunk = self.B if self.groups is not None else min(args.chunk, self.B)
+        self.hm = torch.empty(self.chunk, self.V, h, w, cp, device=dev)
         self.out = torch.empty(self.B, self.J, X, Y, Z, device=dev)
         self.samples = self.B * self.N * self.V
         # volume written once + every heatmap element read once + cameras
@@ -112,17 +118,39 @@ class RootWorkload:
         self.kernel_name = ('unproject_group_kernel<ROOT>' if self.groups is not None
                             else 'unproject_kernel<ROOT>')
 
-    def repack(self):
-        self.ops.repack_nhwc(self.fms, out=self.hm)
+    def _chunks(self):
+        return [(c0, min(self.chunk, self.B - c0)) for c0 in range(0, self.B, self.chunk)]
 
-    def kernel(self):
-        self.ops.unproject_root(self.hm, self.cam, self.axes, self.J,
+    def repack(self, c0=0, n=None):
+        n = self.chunk if n is None else n
+        self.ops.repack_nhwc([f[c0:c0 + n] for f in self.fms], out=self.hm[:n])
+
+    def kernel(self, c0=0, n=None):
+        n = self.chunk if n is None else n
+        self.ops.unproject_root(self.hm[:n], self.cam[c0:c0 + n], self.axes, self.J,
                                 self.cfg['heatmap_size'], self.cfg['image_size'],
-                                out=self.out, groups=self.groups)
+                                out=self.out[c0:c0 + n], groups=self.groups)
 
     def step(self):
-        self.repack()
-        self.kernel()
+        for c0, n in self._chunks():
+            self.repack(c0, n)
+            self.kernel(c0, n)
+
+    def parts(self, steps):
+        """(kernel ms, repack ms) per step and kernel launches per step: HIP events around
+        every launch of the timed steps, on the launch stream."""
+        E = lambda: torch.cuda.Event(enable_timing=True)
+        ks, rs = [], []
+        for _ in range(steps):
+            for c0, n in self._chunks():
+                r0, r1, k0, k1 = E(), E(), E(), E()
+                r0.record(); self.repack(c0, n); r1.record()
+                k0.record(); self.kernel(c0, n); k1.record()
+                rs.append((r0, r1)); ks.append((k0, k1))
+        torch.cuda.synchronize()
+        k_ms = sum(a.elapsed_time(b) for a, b in ks) / steps
+        r_ms = sum(a.elapsed_time(b) for a, b in rs) / steps
+        return k_ms, r_ms, len(self._chunks())
 
 
 class WindowWorkload:
@@ -359,7 +387,8 @@ def measured_traffic(args, wl):
     tag = 'root' if args.workload == 'root' else ('planes' if args.planes == 'only' else 'window')
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01',
                         tag + '_pmc_summary.csv')
-    if args.batch != 32 or (tag != 'root' and args.proposals != 10) or not os.path.exists(path):
+    if (args.batch != 32 or (tag != 'root' and args.proposals != 10) or args.chunk != 8
+            or not os.path.exists(path)):
         return None, None
     vals = {}
     with open(path) as f:
@@ -407,20 +436,24 @@ def main():
         elapsed = float(t.item())
 
     # dominant kernel alone, HIP events on the launch stream
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    rp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    for (a, b), (c, d) in zip(ev, rp):
-        c.record()
-        wl.repack()
-        d.record()
-        a.record()
-        wl.kernel()
-        b.record()
-    torch.cuda.synchronize()
-    k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-    r_ms = sum(c.elapsed_time(d) for c, d in rp) / len(rp)
+    if hasattr(wl, 'parts'):
+        k_ms, r_ms, launches = wl.parts(args.steps)
+    else:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+        rp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for _ in range(args.steps)]
+        for (a, b), (c, d) in zip(ev, rp):
+            c.record()
+            wl.repack()
+            d.record()
+            a.record()
+            wl.kernel()
+            b.record()
+        torch.cuda.synchronize()
+        k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+        r_ms = sum(c.elapsed_time(d) for c, d in rp) / len(rp)
+        launches = 1
 
     # fused epilogue: what the reference's caller does instead (tempo_pose.py:172-176) --
     # the volume kernel followed by torch.max over each axis, on the same inputs
@@ -458,6 +491,9 @@ def main():
         ops = wl.ops
         cp = wl.hm.shape[-1]
         root = args.workload == 'root'
+        if root:  # the training step works on the whole batch at once
+            wl.hm = torch.empty(wl.B, *wl.hm.shape[1:], device=dev)
+            ops.repack_nhwc(wl.fms, out=wl.hm)
         items = wl.B if root else wl.NW
         cmask = ops.new_clamp_mask(items, wl.N, cp, dev)
         gout = torch.rand(wl.out.shape, device=dev)
@@ -529,7 +565,10 @@ def main():
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'traffic_source': traffic_src,
                 'kernel': wl.kernel_name, 'kernel_ms': round(k_ms, 4),
-                'algorithmic_bytes': wl.kernel_bytes},
+                'launches_per_step': launches,
+                'kernel_launch_ms': round(k_ms / launches, 4),
+                'algorithmic_bytes': wl.kernel_bytes,
+                'algorithmic_bytes_per_launch': wl.kernel_bytes // launches},
             'repack_ms': round(r_ms, 4),
             'kernel_gsamp_s': round(wl.samples / (k_ms * 1e-3) / 1e9, 3),
         }

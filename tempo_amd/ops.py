@@ -213,9 +213,62 @@ def unproject_window_backward(grad_cubes, cam, fine_axes, tl, start, end, clamp_
     return ghm
 
 
+ROOT_CHUNK_FRAMES = 8
+
+
+def mask_dtype(num_views):
+    """(bytes, torch dtype) of one valid-view bitmap word for ``num_views`` views."""
+    nbytes = 1 if num_views <= 8 else (2 if num_views <= 16 else 4)
+    return nbytes, {1: torch.uint8, 2: torch.int16, 4: torch.int32}[nbytes]
+
+
+def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, channels=None,
+              live=None, want_grids=False, want_mask=False, out=None, mm_mode='auto',
+              chunk=None, hm_buf=None):
+    """Repack + root unprojection of a whole batch, in chunks of ``chunk`` frames
+    (default 8) that reuse one channel-last buffer: the 80 MB a chunk's maps take
+    stay in the 256 MB Infinity Cache between the repack that writes them and the
+    gather that reads them, instead of making a round trip through HBM (config 2:
+    0.39 -> 0.31 ms per 32-frame step; 8 frames also give each of the 8 XCDs one
+    frame).  Arguments as :func:`repack_nhwc` + :func:`unproject_root`; ``axes``
+    and ``live`` may be per batch item.  Returns ``(cubes, grids | None, mask | None)``."""
+    fm0 = feature_maps[0]
+    dev = fm0.device
+    B, C_total, H, W = fm0.shape
+    V = len(feature_maps)
+    C = C_total - c_begin if channels is None else channels
+    chunk = ROOT_CHUNK_FRAMES if chunk is None else int(chunk)
+    X, Y, Z = (int(a.shape[-1]) for a in axes)
+    N = X * Y * Z
+    if out is None:
+        out = torch.empty(B, C, X, Y, Z, dtype=torch.float32, device=dev)
+    grids = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if want_grids else None
+    mask = torch.empty(B, N, dtype=mask_dtype(V)[1], device=dev) if want_mask else None
+    if B <= chunk:
+        hm = repack_nhwc(feature_maps, c_begin, C, out=None if hm_buf is None else hm_buf[:B])
+        unproject_root(hm, cam, axes, C, heatmap_size, image_size, live=live,
+                       want_grids=want_grids, want_mask=want_mask, out=out, mm_mode=mm_mode,
+                       grids_out=grids, mask_out=mask)
+        return out, grids, mask
+    cp = padded_channels(C)
+    if hm_buf is None:
+        hm_buf = torch.empty(chunk, V, H, W, cp, dtype=torch.float32, device=dev)
+    batched = axes[0].dim() == 2
+    for c0 in range(0, B, chunk):
+        n = min(chunk, B - c0)
+        sl = slice(c0, c0 + n)
+        hm = repack_nhwc([fm[sl] for fm in feature_maps], c_begin, C, out=hm_buf[:n])
+        unproject_root(hm, cam[sl], [a[sl] for a in axes] if batched else axes, C,
+                       heatmap_size, image_size, live=None if live is None else live[sl],
+                       want_grids=want_grids, want_mask=want_mask, out=out[sl],
+                       mm_mode=mm_mode, grids_out=None if grids is None else grids[sl],
+                       mask_out=None if mask is None else mask[sl])
+    return out, grids, mask
+
+
 def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
                    want_grids=False, want_mask=False, out=None, mm_mode='auto',
-                   groups=None, clamp_mask=None):
+                   groups=None, clamp_mask=None, grids_out=None, mask_out=None):
     """Root-grid unprojection on a repacked heatmap tensor.
 
     hm ``[B,V,H,W,CP]``; cam ``[B,V,32]``; axes = (ax_x, ax_y, ax_z), each
@@ -249,12 +302,20 @@ def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
         _need(out, torch.float32, 'out', dev)
         if out.numel() != B * C * N:
             raise ValueError('out has the wrong size')
-    grids = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if want_grids else None
+    grids = None
+    if want_grids:
+        grids = grids_out if grids_out is not None else torch.empty(
+            B, N, 3, dtype=torch.float32, device=dev)
+        _need(grids, torch.float32, 'grids_out', dev)
+        if grids.numel() != B * N * 3:
+            raise ValueError('grids_out has the wrong size')
     mask, mask_bytes = None, 0
     if want_mask:
-        mask_bytes = 1 if V <= 8 else (2 if V <= 16 else 4)
-        mdt = {1: torch.uint8, 2: torch.int16, 4: torch.int32}[mask_bytes]
-        mask = torch.empty(B, N, dtype=mdt, device=dev)
+        mask_bytes, mdt = mask_dtype(V)
+        mask = mask_out if mask_out is not None else torch.empty(B, N, dtype=mdt, device=dev)
+        _need(mask, mdt, 'mask_out', dev)
+        if mask.numel() != B * N:
+            raise ValueError('mask_out has the wrong size')
     groups, ng = _groups_arg(groups, B, dev)
     if clamp_mask is not None:  # training forward: also record the clamp mask
         _check_clamp_mask(clamp_mask, B, N, CP, dev)

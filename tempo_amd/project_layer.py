@@ -238,13 +238,20 @@ class ProjectLayer(nn.Module):
         cubes = torch.empty(B, C, *cube_size, dtype=torch.float32, device=device)
         grids = mask = None
         for c0, cs in _Slices(C).items:
-            hm = ops.repack_nhwc(feature_maps, c0, cs)
             first = c0 == 0
-            out, g, m = ops.unproject_root(
-                hm, cam, axes, cs, self.heatmap_size, self.image_size, live=live,
-                want_grids=first and self.materialize_grids,
-                want_mask=first and self.keep_mask,
-                out=cubes if cs == C else None, mm_mode=self.mm_mode, groups=groups)
+            if groups is None:  # frames in cache-sized chunks (ops.root_step)
+                out, g, m = ops.root_step(
+                    feature_maps, cam, axes, self.heatmap_size, self.image_size, c0, cs,
+                    live=live, want_grids=first and self.materialize_grids,
+                    want_mask=first and self.keep_mask, out=cubes if cs == C else None,
+                    mm_mode=self.mm_mode)
+            else:
+                hm = ops.repack_nhwc(feature_maps, c0, cs)
+                out, g, m = ops.unproject_root(
+                    hm, cam, axes, cs, self.heatmap_size, self.image_size, live=live,
+                    want_grids=first and self.materialize_grids,
+                    want_mask=first and self.keep_mask,
+                    out=cubes if cs == C else None, mm_mode=self.mm_mode, groups=groups)
             if cs != C:
                 cubes[:, c0:c0 + cs] = out
             if first:
