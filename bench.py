@@ -58,6 +58,9 @@ def parse():
     ap.add_argument('--chunk', type=int, default=8,
                     help='root workload: frames per repack+unproject chunk (one reused '
                          'channel-last buffer that stays in the Infinity Cache)')
+    ap.add_argument('--window-chunk', type=int, default=None,
+                    help='window workloads: frames per chunk (default: cache-sized, about 40 '
+                         'windows per launch)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
 
@@ -194,7 +197,14 @@ class WindowWorkload:
                                        dtype=torch.int32, device=dev)
         w, h = cfg['heatmap_size']
         cp = ops.padded_channels(self.J)
-        self.hm = torch.empty(self.B, self.V, h, w, cp, device=dev)
+        # regular batches (window j looks at frame j // P) go through in frame chunks that
+        # reuse one channel-last buffer (ops.window_step); sequences / grouped launches do not
+        self.P = P
+        self.chunk = self.B
+        if T == 1 and self.groups is None and args.planes == 'off':  # (planes: one launch is faster)
+            self.chunk = min(self.B, args.window_chunk or
+                             min(ops.chunk_frames(self.V, h, w, cp), max(1, 40 // P)))
+        self.hm = torch.empty(self.chunk, self.V, h, w, cp, device=dev)
         self.N = self.sub[0] * self.sub[1] * self.sub[2]
         self.planes_mode = args.planes
         self.out = (torch.empty(self.NW, self.J, *self.sub, device=dev)
@@ -212,24 +222,39 @@ class WindowWorkload:
                             else 'unproject_planes_kernel' if args.planes != 'off'
                             else 'unproject_kernel<WINDOW>')
 
-    def repack(self):
-        self.ops.repack_nhwc(self.fms, out=self.hm)
+    def _chunks(self):
+        return [(f0, min(self.chunk, self.B - f0)) for f0 in range(0, self.B, self.chunk)]
 
-    def kernel(self):
-        tl, st, en = self.geo
+    def repack(self, f0=0, n=None):
+        n = self.chunk if n is None else n
+        self.ops.repack_nhwc([f[f0:f0 + n] for f in self.fms], out=self.hm[:n])
+
+    def kernel(self, f0=0, n=None):
+        n = self.chunk if n is None else n
+        whole = n == self.B
+        ws = slice(0, self.NW) if whole else slice(f0 * self.P, (f0 + n) * self.P)
+        tl, st, en = (t[ws] for t in self.geo)
+        # inside a chunk the frames are numbered from 0
+        wf = self.win_frame if whole else (self.win_frame[ws] - f0).contiguous()
+        cam = self.cam if whole else self.cam[f0:f0 + n]
         if self.planes_mode != 'off':
             self.ops.unproject_window_planes(
-                self.hm, self.cam, self.fine, tl, st, en, self.sub, self.J,
-                self.cfg['heatmap_size'], self.cfg['image_size'], win_frame=self.win_frame,
-                want_cubes=self.planes_mode == 'with', out=self.out, planes_out=self.planes)
+                self.hm[:n], cam, self.fine, tl, st, en, self.sub, self.J,
+                self.cfg['heatmap_size'], self.cfg['image_size'], win_frame=wf,
+                want_cubes=self.planes_mode == 'with',
+                out=None if self.out is None else self.out[ws],
+                planes_out=[p[ws] for p in self.planes])
             return
-        self.ops.unproject_window(self.hm, self.cam, self.fine, tl, st, en, self.sub, self.J,
+        self.ops.unproject_window(self.hm[:n], cam, self.fine, tl, st, en, self.sub, self.J,
                                   self.cfg['heatmap_size'], self.cfg['image_size'],
-                                  win_frame=self.win_frame, out=self.out, groups=self.groups)
+                                  win_frame=wf, out=self.out[ws], groups=self.groups)
 
     def step(self):
-        self.repack()
-        self.kernel()
+        for f0, n in self._chunks():
+            self.repack(f0, n)
+            self.kernel(f0, n)
+
+    parts = RootWorkload.parts
 
 
 class WindowH36MWorkload(WindowWorkload):
@@ -461,6 +486,9 @@ def main():
     if rank == 0 and getattr(wl, 'planes_mode', 'off') != 'off':
         vol = wl.out if wl.out is not None else torch.empty(wl.NW, wl.J, *wl.sub, device=dev)
         tl, st, en = wl.geo
+        wl.hm = torch.empty(wl.B, *wl.hm.shape[1:], device=dev)
+        wl.chunk = wl.B
+        wl.ops.repack_nhwc(wl.fms, out=wl.hm)
 
         def unfused_step():
             wl.ops.unproject_window(wl.hm, wl.cam, wl.fine, tl, st, en, wl.sub, wl.J,
@@ -491,8 +519,9 @@ def main():
         ops = wl.ops
         cp = wl.hm.shape[-1]
         root = args.workload == 'root'
-        if root:  # the training step works on the whole batch at once
+        if wl.hm.shape[0] != wl.B:  # the training step works on the whole batch at once
             wl.hm = torch.empty(wl.B, *wl.hm.shape[1:], device=dev)
+            wl.chunk = wl.B
             ops.repack_nhwc(wl.fms, out=wl.hm)
         items = wl.B if root else wl.NW
         cmask = ops.new_clamp_mask(items, wl.N, cp, dev)

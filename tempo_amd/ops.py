@@ -214,6 +214,67 @@ def unproject_window_backward(grad_cubes, cam, fine_axes, tl, start, end, clamp_
 
 
 ROOT_CHUNK_FRAMES = 8
+CHUNK_BYTES = 100e6  # channel-last maps of one chunk: well inside the 256 MB Infinity Cache
+
+
+def chunk_frames(V, H, W, cp, limit=ROOT_CHUNK_FRAMES):
+    """Frames per repack+unproject chunk so that the chunk's channel-last maps stay
+    cache-resident between the two kernels (at most ``limit`` = one frame per XCD)."""
+    return int(max(1, min(limit, CHUNK_BYTES // (V * H * W * cp * 4))))
+
+
+def window_step(feature_maps, cam, fine_axes, tl, start, end, sub_cube, heatmap_size,
+                image_size, windows_per_frame=1, c_begin=0, channels=None, live=None,
+                out=None, planes_out=None, planes=False, want_cubes=True, mm_mode='auto',
+                chunk=None, hm_buf=None):
+    """Repack + window unprojection for a regular batch -- window j looks at frame
+    ``j // windows_per_frame`` -- in chunks of frames that reuse one channel-last
+    buffer (see :func:`root_step`; at the H36M map size the repack otherwise writes
+    6 GB to HBM per 128 frames of which the windows read 5 %).  ``planes=True`` adds
+    the fused axis-max planes (:func:`unproject_window_planes`).  Returns
+    ``(cubes | None, planes | None)``."""
+    fm0 = feature_maps[0]
+    dev = fm0.device
+    F_, C_total, H, W = fm0.shape
+    V = len(feature_maps)
+    C = C_total - c_begin if channels is None else channels
+    P = int(windows_per_frame)
+    NW = int(tl.shape[0])
+    if NW != F_ * P:
+        raise ValueError('window_step needs windows_per_frame windows for every frame, in order')
+    cp = padded_channels(C)
+    if chunk is None:  # cache-sized, and about 40 windows per launch (measured best)
+        chunk = min(chunk_frames(V, H, W, cp), max(1, 40 // P))
+        if planes:  # the column-walk kernel has long workgroups: one launch is faster
+            chunk = F_
+    chunk = int(chunk)
+    vx, vy, vz = (int(v) for v in sub_cube)
+    if want_cubes and out is None:
+        out = torch.empty(NW, C, vx, vy, vz, dtype=torch.float32, device=dev)
+    if planes and planes_out is None:
+        planes_out = [torch.empty(NW, C, *sh, dtype=torch.float32, device=dev)
+                      for sh in ((vx, vy), (vx, vz), (vy, vz))]
+    if hm_buf is None:
+        hm_buf = torch.empty(min(chunk, F_), V, H, W, cp, dtype=torch.float32, device=dev)
+    for f0 in range(0, F_, chunk):
+        n = min(chunk, F_ - f0)
+        fs, ws = slice(f0, f0 + n), slice(f0 * P, (f0 + n) * P)
+        hm = repack_nhwc([fm[fs] for fm in feature_maps], c_begin, C, out=hm_buf[:n])
+        wf = None
+        if P != 1:
+            wf = (torch.arange(n * P, device=dev, dtype=torch.int32) // P).contiguous()
+        lv = None if live is None else live[ws]
+        if planes:
+            unproject_window_planes(hm, cam[fs], fine_axes, tl[ws], start[ws], end[ws], sub_cube,
+                                    C, heatmap_size, image_size, win_frame=wf, live=lv,
+                                    want_cubes=want_cubes, mm_mode=mm_mode,
+                                    out=out[ws] if want_cubes else None,
+                                    planes_out=[p[ws] for p in planes_out])
+        else:
+            unproject_window(hm, cam[fs], fine_axes, tl[ws], start[ws], end[ws], sub_cube, C,
+                             heatmap_size, image_size, win_frame=wf, live=lv, out=out[ws],
+                             mm_mode=mm_mode)
+    return (out if want_cubes else None), (planes_out if planes else None)
 
 
 def mask_dtype(num_views):

@@ -420,11 +420,10 @@ class ProjectLayerWithMask(nn.Module):
             return cubes, offset
         cubes = torch.empty(B, C, *self._sub_cube, dtype=torch.float32, device=device)
         for c0, cs in _Slices(C).items:
-            hm = ops.repack_nhwc(feature_maps, c0, cs)
-            out = ops.unproject_window(
-                hm, cam, self._fine_axes, tl, st, en, self._sub_cube, cs,
-                self.heatmap_size, self.image_size, live=live,
-                out=cubes if cs == C else None, mm_mode=self.mm_mode)
+            out, _ = ops.window_step(
+                feature_maps, cam, self._fine_axes, tl, st, en, self._sub_cube,
+                self.heatmap_size, self.image_size, windows_per_frame=1, c_begin=c0,
+                channels=cs, live=live, out=cubes if cs == C else None, mm_mode=self.mm_mode)
             if cs != C:
                 cubes[:, c0:c0 + cs] = out
         return cubes, offset

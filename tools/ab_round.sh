@@ -1,6 +1,21 @@
 #!/bin/bash
-# GPU tests, then the training-step timing (run through gpurun from the repo root)
-timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread -s > gpurun_out/gputests.log 2>&1
-grep -E "grad max-abs|passed|failed|Error" gpurun_out/gputests.log | tail -20
-timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --backward > gpurun_out/bwd_root.log 2>&1 && timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --backward --workload window > gpurun_out/bwd_win.log 2>&1
-grep -o "training_step.*" gpurun_out/bwd_root.log gpurun_out/bwd_win.log
+# bench lines for every workload (run through gpurun from the repo root)
+rm -f gpurun_out/ab.log
+for args in "" "--backward" "--workload window" "--workload window --backward --steps 5 --warmup 2" "--workload window --planes with" "--workload window --planes only" "--workload window_h36m --batch 128" "--workload window_h36m --batch 128 --planes only" "--workload window --timesteps 4 --share" "--workload dense"; do
+  echo "== $args" >> gpurun_out/ab.log
+  timeout -k 10 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline $args 2>&1 | grep -v amdgpu.ids >> gpurun_out/ab.log || { echo FAILED >> gpurun_out/ab.log; break; }
+done
+python - <<'PY'
+import json
+for line in open('gpurun_out/ab.log'):
+    if line.startswith('=='):
+        print(line.strip()); continue
+    try:
+        d = json.loads(line)
+    except Exception:
+        print(line.strip()[:300]); continue
+    r = d['roofline']
+    print('  value %.2f Gsamp/s  step %.4f ms  kernel %.4f ms (%d launches)  repack %.4f  frac %.3f' % (
+        d['value'], d['ms_per_step'], r['kernel_ms'], r['launches_per_step'], d['repack_ms'], r['frac']),
+        {k: d[k] for k in ('unfused_consumer', 'training_step') if k in d})
+PY
