@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define TEMPO_ABI_VERSION 3
+#define TEMPO_ABI_VERSION 4
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
@@ -102,6 +102,24 @@ int tempo_unproject_root(const float* hm, const float* cam, const float* ax_x,
                          int CP, int H, int W, int X, int Y, int Z, float hm_w,
                          float hm_h, float img_w, float img_h, int mm_unfused,
                          void* stream);
+
+/* Whole root step for a batch, NCHW maps in, volume out: tempo_repack_nhwc +
+ * tempo_unproject_root over chunks of `chunk` frames that reuse ONE channel-last
+ * buffer (`workspace`): choose chunk so that a chunk's maps take <= ~100 MB (8
+ * frames at the Panoptic sizes) and they stay in the MI355X's 256 MB Infinity
+ * Cache between the repack that writes them and the gather that reads them.
+ * Results are those of the two separate calls on the whole batch.
+ *   views     : HOST array of V device pointers, fp32 [B, C_total, H, W]
+ *   workspace : device fp32 [tempo_root_step_workspace(B, V, H, W, CP, chunk)]
+ *   cam, ax_*, live, cubes, grids, mask : as tempo_unproject_root, for all B items */
+long long tempo_root_step_workspace(int B, int V, int H, int W, int CP, int chunk);
+int tempo_root_step(const void* const* views, int C_total, int c_begin,
+                    const float* cam, const float* ax_x, const float* ax_y,
+                    const float* ax_z, int ax_batched, const uint8_t* live,
+                    float* cubes, float* grids, void* mask, int mask_bytes, int B,
+                    int V, int C, int CP, int H, int W, int X, int Y, int Z,
+                    float hm_w, float hm_h, float img_w, float img_h,
+                    int mm_unfused, float* workspace, int chunk, void* stream);
 
 /* tempo_unproject_root for a batch in which runs of consecutive items share one
  * calibration and one grid -- the frames of one recording; the reference

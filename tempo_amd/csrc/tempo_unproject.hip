@@ -533,14 +533,13 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
   __builtin_amdgcn_wave_barrier();
 }
 
+// One workgroup of the tile kernel; `bid` is its position in the launch order.
 template <int MODE, int L, int SB, int UNF>
-__global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-
+__device__ __forceinline__ void unproject_block(const UnprojArgs& a, int bid,
+                                                unsigned char* smem) {
   // XCD-aware work order: workgroups b, b+8, b+16.. share an XCD (and its L2);
   // give each such group one contiguous run of (batch item, tile) pairs so an
   // XCD's L2 holds the heatmaps of one frame at a time.
-  const int bid = blockIdx.x;
   const int run = bid >> 3;
   const int item = (bid & 7) * a.chunk + run;
   if (run >= a.chunk || item >= a.total) return;
@@ -586,6 +585,12 @@ __global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a)
   }
   if (a.pl01 != nullptr || a.pl02 != nullptr || a.pl12 != nullptr)
     planes_epilogue(a, b, n0, lane, s_out, TSTR);
+}
+
+template <int MODE, int L, int SB, int UNF>
+__global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unproject_block<MODE, L, SB, UNF>(a, blockIdx.x, smem);
 }
 
 // --------------------------------------------- window + axis-max planes, fused
@@ -1187,6 +1192,7 @@ struct RepackArgs {
   const float* views[TEMPO_MAX_VIEWS];
   float* out;
   int V, B, C_total, c_begin, C, HW, CP;
+  int b0;  // first frame of the source tensors to take (out is numbered from 0)
 };
 
 constexpr int kRepackPix = 64;
@@ -1197,7 +1203,7 @@ __global__ __launch_bounds__(kThreads) void repack_kernel(const RepackArgs a) {
   const int p0 = blockIdx.x * kRepackPix;
   const int v = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* in = a.views[v] + ((long long)b * a.C_total + a.c_begin) * a.HW;
+  const float* in = a.views[v] + ((long long)(b + a.b0) * a.C_total + a.c_begin) * a.HW;
   for (int c = wave; c < a.CP; c += 4) {
     float val = 0.0f;
     if (c < a.C && p0 + lane < a.HW) val = in[(long long)c * a.HW + p0 + lane];
@@ -1225,12 +1231,11 @@ constexpr int kWidePix = 256;
 constexpr int kWideStr = kWidePix + 2;
 
 template <int L>
-__global__ __launch_bounds__(kThreads) void repack_wide_kernel(const RepackArgs a) {
-  __shared__ __attribute__((aligned(16))) float s[4 * L * kWideStr];
-  const int p0 = blockIdx.x * kWidePix;
-  const int v = blockIdx.y, b = blockIdx.z;
+__device__ __forceinline__ void repack_wide_block(const RepackArgs& a, int bx, int v, int b,
+                                                  float* s) {
+  const int p0 = bx * kWidePix;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* in = a.views[v] + ((long long)b * a.C_total + a.c_begin) * a.HW;
+  const float* in = a.views[v] + ((long long)(b + a.b0) * a.C_total + a.c_begin) * a.HW;
   const int p = p0 + 4 * lane;
   float4 r[L];
 #pragma unroll
@@ -1260,6 +1265,12 @@ __global__ __launch_bounds__(kThreads) void repack_wide_kernel(const RepackArgs 
       out[i] = make_float4(col[0], col[kWideStr], col[2 * kWideStr], col[3 * kWideStr]);
     }
   }
+}
+
+template <int L>
+__global__ __launch_bounds__(kThreads) void repack_wide_kernel(const RepackArgs a) {
+  __shared__ __attribute__((aligned(16))) float s[4 * L * kWideStr];
+  repack_wide_block<L>(a, blockIdx.x, blockIdx.y, blockIdx.z, s);
 }
 
 template <int L>
@@ -1477,7 +1488,7 @@ int tempo_repack_nhwc(const void* const* views, int V, int B, int C_total, int c
   for (int v = V; v < TEMPO_MAX_VIEWS; v++) a.views[v] = nullptr;
   a.out = out;
   a.V = V; a.B = B; a.C_total = C_total; a.c_begin = c_begin; a.C = C;
-  a.HW = H * W; a.CP = CP;
+  a.HW = H * W; a.CP = CP; a.b0 = 0;
   bool wide = a.HW % 4 == 0 && (((long long)C_total * a.HW) % 4 == 0) &&
               (((long long)c_begin * a.HW) % 4 == 0);
   for (int v = 0; v < V; v++) wide = wide && (reinterpret_cast<uintptr_t>(views[v]) % 16 == 0);
@@ -1665,6 +1676,50 @@ int root_impl(const float* hm, const float* cam, const float* ax_x, const float*
 }  // namespace
 
 extern "C" {
+
+long long tempo_root_step_workspace(int B, int V, int H, int W, int CP, int chunk) {
+  if (B <= 0 || V <= 0 || H <= 0 || W <= 0 || CP <= 0 || chunk <= 0) return TEMPO_E_DIM;
+  return (long long)(B < chunk ? B : chunk) * V * H * W * CP;
+}
+
+int tempo_root_step(const void* const* views, int C_total, int c_begin, const float* cam,
+                    const float* ax_x, const float* ax_y, const float* ax_z, int ax_batched,
+                    const uint8_t* live, float* cubes, float* grids, void* mask,
+                    int mask_bytes, int B, int V, int C, int CP, int H, int W, int X, int Y,
+                    int Z, float hm_w, float hm_h, float img_w, float img_h, int mm_unfused,
+                    float* workspace, int chunk, void* stream) {
+  if (views == nullptr || workspace == nullptr || cam == nullptr || cubes == nullptr)
+    return TEMPO_E_NULL;
+  const int rc = check_common(V, C, CP, H, W);
+  if (rc != TEMPO_OK) return rc;
+  if (B <= 0 || B > 65535 || chunk <= 0 || c_begin < 0 || c_begin + C > C_total ||
+      X <= 0 || Y <= 0 || Z <= 0)
+    return TEMPO_E_DIM;
+  if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
+  for (int v = 0; v < V; v++)
+    if (views[v] == nullptr) return TEMPO_E_NULL;
+  const long long HW = (long long)H * W;
+  const long long N = (long long)X * Y * Z;
+  const void* shifted[TEMPO_MAX_VIEWS];
+  int err = TEMPO_OK;
+  for (int b0 = 0; b0 < B && err == TEMPO_OK; b0 += chunk) {
+    const int n = b0 + chunk <= B ? chunk : B - b0;
+    for (int v = 0; v < V; v++)
+      shifted[v] = static_cast<const float*>(views[v]) + (long long)b0 * C_total * HW;
+    err = tempo_repack_nhwc(shifted, V, n, C_total, c_begin, C, H, W, CP, workspace, stream);
+    if (err != TEMPO_OK) break;
+    err = root_impl(workspace, cam + (long long)b0 * V * CAM_FLOATS,
+                    ax_x + (ax_batched ? (long long)b0 * X : 0),
+                    ax_y + (ax_batched ? (long long)b0 * Y : 0),
+                    ax_z + (ax_batched ? (long long)b0 * Z : 0), ax_batched,
+                    live ? live + b0 : nullptr, cubes + (long long)b0 * C * N,
+                    grids ? grids + (long long)b0 * N * 3 : nullptr,
+                    mask ? static_cast<char*>(mask) + (long long)b0 * N * mask_bytes : nullptr,
+                    mask_bytes, n, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w, img_h,
+                    mm_unfused, nullptr, 0, Extra(), stream);
+  }
+  return err;
+}
 
 int tempo_unproject_window(const float* hm, const float* cam, const int32_t* win_frame,
                            const float* fx, const float* fy, const float* fz,

@@ -285,7 +285,7 @@ def mask_dtype(num_views):
 
 def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, channels=None,
               live=None, want_grids=False, want_mask=False, out=None, mm_mode='auto',
-              chunk=None, hm_buf=None):
+              chunk=None, hm_buf=None, in_library=True):
     """Repack + root unprojection of a whole batch, in chunks of ``chunk`` frames
     (default 8) that reuse one channel-last buffer: the 80 MB a chunk's maps take
     stay in the 256 MB Infinity Cache between the repack that writes them and the
@@ -305,6 +305,9 @@ def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, chan
         out = torch.empty(B, C, X, Y, Z, dtype=torch.float32, device=dev)
     grids = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if want_grids else None
     mask = torch.empty(B, N, dtype=mask_dtype(V)[1], device=dev) if want_mask else None
+    if in_library:  # the same chunk loop inside the library: one call, no per-chunk host work
+        return _root_step_library(feature_maps, cam, axes, heatmap_size, image_size, c_begin, C,
+                                live, out, grids, mask, mm_mode, chunk, hm_buf)
     if B <= chunk:
         hm = repack_nhwc(feature_maps, c_begin, C, out=None if hm_buf is None else hm_buf[:B])
         unproject_root(hm, cam, axes, C, heatmap_size, image_size, live=live,
@@ -324,6 +327,62 @@ def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, chan
                        want_grids=want_grids, want_mask=want_mask, out=out[sl],
                        mm_mode=mm_mode, grids_out=None if grids is None else grids[sl],
                        mask_out=None if mask is None else mask[sl])
+    return out, grids, mask
+
+
+def root_step_workspace(B, V, H, W, cp, chunk, device):
+    """Workspace of :func:`root_step`: the channel-last maps of one chunk."""
+    n = _lib.load().tempo_root_step_workspace(B, V, H, W, cp, chunk)
+    _lib.check(min(int(n), 0), 'tempo_root_step_workspace')
+    return torch.empty(int(n), dtype=torch.float32, device=device)
+
+
+def _root_step_library(feature_maps, cam, axes, heatmap_size, image_size, c_begin, C, live, out,
+                     grids, mask, mm_mode, chunk, workspace):
+    """``tempo_root_step``: the chunk loop of :func:`root_step` inside the library."""
+    lib = _lib.load()
+    fm0 = feature_maps[0]
+    dev = fm0.device
+    B, C_total, H, W = fm0.shape
+    V = len(feature_maps)
+    cp = padded_channels(C)
+    keep = []
+    for i, fm in enumerate(feature_maps):
+        if tuple(fm.shape) != (B, C_total, H, W):
+            raise ValueError('feature maps of all views must share one shape')
+        if fm.dtype != torch.float32:
+            fm = fm.float()
+        keep.append(_need(fm.contiguous(), torch.float32, f'feature_maps[{i}]', dev))
+    _need(cam, torch.float32, 'cam', dev)
+    if tuple(cam.shape) != (B, V, 32):
+        raise ValueError(f'cam must be [{B},{V},32], got {tuple(cam.shape)}')
+    ax = [_need(a, torch.float32, 'axes', dev) for a in axes]
+    batched = ax[0].dim() == 2
+    for a in ax:
+        if (a.dim() == 2) != batched or (batched and a.shape[0] != B):
+            raise ValueError('axes must be all [n] or all [B,n]')
+    X, Y, Z = (int(a.shape[-1]) for a in ax)
+    if live is not None:
+        _need(live, torch.uint8, 'live', dev)
+        if live.numel() != B:
+            raise ValueError('live must have B entries')
+    _need(out, torch.float32, 'out', dev)
+    if out.numel() != B * C * X * Y * Z:
+        raise ValueError('out has the wrong size')
+    need = int(lib.tempo_root_step_workspace(B, V, H, W, cp, chunk))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.float32, device=dev)
+    _need(workspace, torch.float32, 'workspace', dev)
+    mask_bytes = 0 if mask is None else mask_dtype(V)[0]
+    ptrs = (ctypes.c_void_p * V)(*[fm.data_ptr() for fm in keep])
+    with torch.cuda.device(dev):
+        rc = lib.tempo_root_step(
+            ptrs, C_total, c_begin, _ptr(cam), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]),
+            int(batched), _ptr(live), _ptr(out), _ptr(grids), _ptr(mask), mask_bytes, B, V, C,
+            cp, H, W, X, Y, Z, float(heatmap_size[0]), float(heatmap_size[1]),
+            float(image_size[0]), float(image_size[1]), numerics.abi_flag(mm_mode),
+            _ptr(workspace), int(chunk), _stream_ptr(dev))
+    _lib.check(rc, 'tempo_root_step')
     return out, grids, mask
 
 

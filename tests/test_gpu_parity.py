@@ -371,3 +371,34 @@ def test_planes_kernel_dispatch_edges(dims, gpu_device):
     for p, q, dim in ((pxy, qxy, 4), (pxz, qxz, 3), (pyz, qyz, 2)):
         ref = vol.max(dim=dim)[0]
         assert torch.equal(canon(p), canon(ref)) and torch.equal(canon(q), canon(ref))
+
+
+def test_root_step_library_loop_equals_separate_calls(gpu_device):
+    """tempo_root_step (chunk loop inside the library) vs repack + unproject on the whole
+    batch: volume, grids and mask bit-identical, ragged last chunk, per-item centres, a
+    skipped item."""
+    from tempo_amd import ops, synthetic as S
+    from tempo_amd.camera import pack_cameras
+    cfg = S.PANOPTIC
+    B, cube = 7, [12, 10, 9]
+    cams = S.ring_cameras(5, seed=91, target=cfg['space_center'])
+    centers, scales, cameras = S.frame_meta(cams, B, cfg['raw_size'], cfg['image_size'])
+    cam = pack_cameras(centers, scales, cameras, cfg['image_size']).to(gpu_device)
+    w, h = cfg['heatmap_size']
+    fms = [f.to(gpu_device) for f in S.make_heatmaps(B, 5, cfg['num_joints'], h, w,
+                                                     kind='noise', seed=92)]
+    g = torch.Generator().manual_seed(93)
+    axes = [(torch.linspace(-s / 2, s / 2, n)[None, :] + c +
+             torch.rand(B, 1, generator=g) * 200).contiguous().to(gpu_device)
+            for s, n, c in zip(cfg['space_size'], cube, cfg['space_center'])]
+    live = torch.tensor([1, 1, 0, 1, 1, 1, 1], dtype=torch.uint8, device=gpu_device)
+    hm = ops.repack_nhwc(fms)
+    ref = ops.unproject_root(hm, cam, axes, cfg['num_joints'], cfg['heatmap_size'],
+                             cfg['image_size'], live=live, want_grids=True, want_mask=True)
+    for chunk, lib in ((3, True), (3, False), (8, True), (1, True)):
+        got = ops.root_step(fms, cam, axes, cfg['heatmap_size'], cfg['image_size'], live=live,
+                            want_grids=True, want_mask=True, chunk=chunk, in_library=lib)
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            assert torch.equal(torch.nan_to_num(a.float(), nan=-1.0),
+                               torch.nan_to_num(b.float(), nan=-1.0)), (chunk, lib)
