@@ -103,6 +103,20 @@ int tempo_unproject_root(const float* hm, const float* cam, const float* ax_x,
                          float hm_h, float img_w, float img_h, int mm_unfused,
                          void* stream);
 
+/* tempo_unproject_root that also emits the volume's maximum over z, the first
+ * thing the root detector computes from it (center_net.py:230, torch.max(x,
+ * dim=4)); the volume is still written (its z-columns are gathered later,
+ * tempo_detector.py:204-206).
+ *   zmax : out fp32 [B, C, X, Y], bit-identical to torch.max over the volume
+ *          (NaN propagates); cleared on `stream` before the launch. */
+int tempo_unproject_root_zmax(const float* hm, const float* cam, const float* ax_x,
+                              const float* ax_y, const float* ax_z, int ax_batched,
+                              const uint8_t* live, float* cubes, float* grids,
+                              void* mask, int mask_bytes, int B, int V, int C, int CP,
+                              int H, int W, int X, int Y, int Z, float hm_w,
+                              float hm_h, float img_w, float img_h, int mm_unfused,
+                              float* zmax, void* stream);
+
 /* Whole root step for a batch, NCHW maps in, volume out: tempo_repack_nhwc +
  * tempo_unproject_root over chunks of `chunk` frames that reuse ONE channel-last
  * buffer (`workspace`): choose chunk so that a chunk's maps take <= ~100 MB (8

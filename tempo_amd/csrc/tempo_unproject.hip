@@ -184,6 +184,20 @@ __device__ __forceinline__ void planes_epilogue(const UnprojArgs& a, int b, int 
   if (on) voxel_index(a, n, &i0, &i1, &i2);
   const bool column = a.dim[2] == kWaveVox;  // n0 is a multiple of 64: one whole column
   const long long bc = (long long)b * a.C;
+  // shorter columns (the root grid's 20 planes): the lanes of one column are
+  // consecutive, so a segmented shift-and-max leaves the column's maximum in its
+  // first lane and only that lane issues the atomic (a column may continue in
+  // the next wave)
+  const int col = on ? n - i2 : -1 - lane;
+  bool same[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    // (the shuffle runs on every lane: a cross-lane read of an inactive lane gives 0)
+    const int other = __shfl_down(col, 1 << k);
+    same[k] = lane + (1 << k) < kWaveVox && other == col;
+  }
+  const int before = __shfl_up(col, 1);
+  const bool head = lane == 0 || before != col;
   for (int ch = 0; ch < a.C; ch++) {
     const unsigned v = on ? __float_as_uint(s_out[ch * tstr + lane]) : 0u;
     if (v != 0u) {
@@ -199,8 +213,16 @@ __device__ __forceinline__ void planes_epilogue(const UnprojArgs& a, int b, int 
       if (column) {
         const unsigned m = wave_umax_to_lane63(v);
         if (lane == 63) *dst = m;
-      } else if (v != 0u) {
-        __hip_atomic_fetch_max(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        unsigned m = v;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          if ((1 << k) >= a.dim[2]) break;  // no column is longer than dim[2] lanes
+          const unsigned o = __shfl_down(m, 1 << k);
+          if (same[k]) m = o > m ? o : m;
+        }
+        if (head && m != 0u)
+          __hip_atomic_fetch_max(dst, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -1431,6 +1453,7 @@ bool backward_fits(int V, int CP) {
 }
 
 struct Extra {
+  float* zmax = nullptr;                // root forward: max over z, [B][C][X][Y]
   unsigned long long* cmask = nullptr;  // forward: record / backward: read the clamp mask
   float* ghm = nullptr;                 // backward: gradient of the heatmaps (accumulated)
 };
@@ -1530,6 +1553,20 @@ int tempo_unproject_root_grouped(const float* hm, const float* cam, const float*
   return root_impl(hm, cam, ax_x, ax_y, ax_z, ax_batched, live, cubes, grids, mask, mask_bytes,
                    B, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w, img_h, mm_unfused, groups,
                    num_groups, Extra(), stream);
+}
+
+int tempo_unproject_root_zmax(const float* hm, const float* cam, const float* ax_x,
+                              const float* ax_y, const float* ax_z, int ax_batched,
+                              const uint8_t* live, float* cubes, float* grids, void* mask,
+                              int mask_bytes, int B, int V, int C, int CP, int H, int W,
+                              int X, int Y, int Z, float hm_w, float hm_h, float img_w,
+                              float img_h, int mm_unfused, float* zmax, void* stream) {
+  if (!zmax) return TEMPO_E_NULL;
+  Extra ex;
+  ex.zmax = zmax;
+  return root_impl(hm, cam, ax_x, ax_y, ax_z, ax_batched, live, cubes, grids, mask, mask_bytes,
+                   B, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w, img_h, mm_unfused, nullptr, 0,
+                   ex, stream);
 }
 
 int tempo_clamp_mask_words(int num_voxels, int CP) {
@@ -1669,6 +1706,12 @@ int root_impl(const float* hm, const float* cam, const float* ax_x, const float*
                                         (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     return launch_backward<MODE_ROOT>(a, mm_unfused, (hipStream_t)stream);
+  }
+  if (ex.zmax != nullptr) {  // max-accumulated: starts at +0.0, the smallest clamped value
+    const hipError_t e = hipMemsetAsync(ex.zmax, 0, (size_t)B * C * X * Y * sizeof(float),
+                                        (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    a.pl01 = reinterpret_cast<unsigned*>(ex.zmax);
   }
   return launch_mode<MODE_ROOT>(a, mm_unfused, (hipStream_t)stream);
 }

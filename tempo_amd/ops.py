@@ -285,7 +285,7 @@ def mask_dtype(num_views):
 
 def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, channels=None,
               live=None, want_grids=False, want_mask=False, out=None, mm_mode='auto',
-              chunk=None, hm_buf=None, in_library=True):
+              chunk=None, hm_buf=None, in_library=True, zmax_out=None):
     """Repack + root unprojection of a whole batch, in chunks of ``chunk`` frames
     (default 8) that reuse one channel-last buffer: the 80 MB a chunk's maps take
     stay in the 256 MB Infinity Cache between the repack that writes them and the
@@ -305,6 +305,10 @@ def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, chan
         out = torch.empty(B, C, X, Y, Z, dtype=torch.float32, device=dev)
     grids = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if want_grids else None
     mask = torch.empty(B, N, dtype=mask_dtype(V)[1], device=dev) if want_mask else None
+    if zmax_out is not None:
+        in_library = False  # (the z-max rides on the per-chunk call)
+        if tuple(zmax_out.shape) != (B, C, X, Y):
+            raise ValueError(f'zmax_out must be [{B},{C},{X},{Y}]')
     if in_library:  # the same chunk loop inside the library: one call, no per-chunk host work
         return _root_step_library(feature_maps, cam, axes, heatmap_size, image_size, c_begin, C,
                                 live, out, grids, mask, mm_mode, chunk, hm_buf)
@@ -312,7 +316,7 @@ def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, chan
         hm = repack_nhwc(feature_maps, c_begin, C, out=None if hm_buf is None else hm_buf[:B])
         unproject_root(hm, cam, axes, C, heatmap_size, image_size, live=live,
                        want_grids=want_grids, want_mask=want_mask, out=out, mm_mode=mm_mode,
-                       grids_out=grids, mask_out=mask)
+                       grids_out=grids, mask_out=mask, zmax_out=zmax_out)
         return out, grids, mask
     cp = padded_channels(C)
     if hm_buf is None:
@@ -326,7 +330,8 @@ def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, chan
                        heatmap_size, image_size, live=None if live is None else live[sl],
                        want_grids=want_grids, want_mask=want_mask, out=out[sl],
                        mm_mode=mm_mode, grids_out=None if grids is None else grids[sl],
-                       mask_out=None if mask is None else mask[sl])
+                       mask_out=None if mask is None else mask[sl],
+                       zmax_out=None if zmax_out is None else zmax_out[sl])
     return out, grids, mask
 
 
@@ -388,7 +393,7 @@ def _root_step_library(feature_maps, cam, axes, heatmap_size, image_size, c_begi
 
 def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
                    want_grids=False, want_mask=False, out=None, mm_mode='auto',
-                   groups=None, clamp_mask=None, grids_out=None, mask_out=None):
+                   groups=None, clamp_mask=None, grids_out=None, mask_out=None, zmax_out=None):
     """Root-grid unprojection on a repacked heatmap tensor.
 
     hm ``[B,V,H,W,CP]``; cam ``[B,V,32]``; axes = (ax_x, ax_y, ax_z), each
@@ -437,6 +442,21 @@ def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
         if mask.numel() != B * N:
             raise ValueError('mask_out has the wrong size')
     groups, ng = _groups_arg(groups, B, dev)
+    if zmax_out is not None:  # also the volume's maximum over z (center_net.py:230)
+        _need(zmax_out, torch.float32, 'zmax_out', dev)
+        if zmax_out.numel() != B * C * X * Y:
+            raise ValueError('zmax_out must be [B,C,X,Y]')
+        if groups is not None or clamp_mask is not None:
+            raise ValueError('zmax_out cannot be combined with groups or clamp_mask')
+        with torch.cuda.device(dev):
+            rc = lib.tempo_unproject_root_zmax(
+                _ptr(hm), _ptr(cam), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), int(batched),
+                _ptr(live), _ptr(out), _ptr(grids), _ptr(mask), mask_bytes, B, V, C, CP, H,
+                W, X, Y, Z, float(heatmap_size[0]), float(heatmap_size[1]),
+                float(image_size[0]), float(image_size[1]), numerics.abi_flag(mm_mode),
+                _ptr(zmax_out), _stream_ptr(dev))
+        _lib.check(rc, 'tempo_unproject_root_zmax')
+        return out, grids, mask
     if clamp_mask is not None:  # training forward: also record the clamp mask
         _check_clamp_mask(clamp_mask, B, N, CP, dev)
         with torch.cuda.device(dev):

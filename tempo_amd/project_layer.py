@@ -140,6 +140,10 @@ class ProjectLayer(nn.Module):
         self.last_mask = None  # valid-view bitmap of the last call when keep_mask
         self.keep_mask = False
         self.materialize_grids = True  # the reference's 2nd return; callers drop it
+        # extension: keep torch.max(cubes, dim=4) of the last (inference) call in
+        # ``last_zmax`` -- what CenterNet computes first (center_net.py:230)
+        self.keep_zmax = False
+        self.last_zmax = None
         self._axes_cache = {}
         # batch items with bit-identical camera records and grid centre (frames of
         # one recording) share one projection per voxel; results do not change
@@ -237,14 +241,20 @@ class ProjectLayer(nn.Module):
             return cubes, meta.get('grids')
         cubes = torch.empty(B, C, *cube_size, dtype=torch.float32, device=device)
         grids = mask = None
+        zmax = (torch.empty(B, C, cube_size[0], cube_size[1], dtype=torch.float32,
+                            device=device) if self.keep_zmax and groups is None else None)
         for c0, cs in _Slices(C).items:
             first = c0 == 0
             if groups is None:  # frames in cache-sized chunks (ops.root_step)
+                zs = None if zmax is None else (zmax if cs == C else torch.empty(
+                    B, cs, cube_size[0], cube_size[1], dtype=torch.float32, device=device))
                 out, g, m = ops.root_step(
                     feature_maps, cam, axes, self.heatmap_size, self.image_size, c0, cs,
                     live=live, want_grids=first and self.materialize_grids,
                     want_mask=first and self.keep_mask, out=cubes if cs == C else None,
-                    mm_mode=self.mm_mode)
+                    mm_mode=self.mm_mode, zmax_out=zs)
+                if zs is not None and cs != C:
+                    zmax[:, c0:c0 + cs] = zs
             else:
                 hm = ops.repack_nhwc(feature_maps, c0, cs)
                 out, g, m = ops.unproject_root(
@@ -257,6 +267,7 @@ class ProjectLayer(nn.Module):
             if first:
                 grids, mask = g, m
         self.last_mask = mask
+        self.last_zmax = zmax
         return cubes, grids
 
     def forward(self, feature_maps, grid_size, grid_center, cube_size, centers,

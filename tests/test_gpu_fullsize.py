@@ -57,6 +57,18 @@ def test_config1_one_frame_full_root_grid(gpu_device):
     _check_root(dict(cfg='panoptic', B=1, cube=[80, 80, 20], hm='noise', seed=101), gpu_device)
 
 
+def test_root_zmax_full_grid(gpu_device):
+    """80x80x20 (20-voxel columns, 3.2 per wave) and 128^3 z-slab of 16: z-max vs torch.max."""
+    for spec in (dict(cfg='panoptic', B=2, cube=[80, 80, 20], hm='noise', seed=110),
+                 dict(cfg='panoptic', B=1, cube=[32, 32, 64], hm='noise', seed=111),
+                 dict(cfg='panoptic', B=1, cube=[24, 24, 7], hm='blobs', seed=112)):
+        case, dcase, layer = _root_pair(spec, gpu_device)
+        layer.keep_zmax = True
+        with torch.no_grad():
+            cubes, _ = layer(*dcase['args'])
+        assert _same(layer.last_zmax, cubes.max(dim=4)[0])
+
+
 @pytest.mark.parametrize('views', [7, 10, 13])
 def test_dense_many_views(views, gpu_device):
     """configs[4] reduced: 10 (and 7, 13) views -- the view sum runs in torch's

@@ -402,3 +402,18 @@ def test_root_step_library_loop_equals_separate_calls(gpu_device):
         for a, b in zip(got, ref):
             assert torch.equal(torch.nan_to_num(a.float(), nan=-1.0),
                                torch.nan_to_num(b.float(), nan=-1.0)), (chunk, lib)
+
+
+@pytest.mark.parametrize('name', list(cases.ROOT_CASES))
+def test_root_zmax_equals_torch_max(name, gpu_device):
+    """center_net.py:230: the z-max plane emitted by the kernel (columns shorter than a
+    wave, straddling waves) is bit-identical to torch.max over the volume."""
+    import tempo_amd
+    case = cases.to_device(cases.build_root(name), gpu_device)
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    layer.keep_zmax = True
+    with torch.no_grad():
+        cubes, _ = layer(*case['args'])
+    canon = lambda t: torch.nan_to_num(t, nan=-1.0)
+    assert layer.last_zmax.shape == cubes.shape[:4]
+    assert torch.equal(canon(layer.last_zmax), canon(cubes.max(dim=4)[0]))
