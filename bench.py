@@ -135,9 +135,15 @@ class RootWorkload:
                                 out=self.out[c0:c0 + n], groups=self.groups)
 
     def step(self):
-        for c0, n in self._chunks():
-            self.repack(c0, n)
-            self.kernel(c0, n)
+        if self.groups is not None:
+            self.repack(0, self.B)
+            self.kernel(0, self.B)
+            return
+        # one library call: tempo_root_step runs the chunk loop (repack + unprojection per
+        # chunk, one reused channel-last workspace)
+        self.ops.root_step(self.fms, self.cam, self.axes, self.cfg['heatmap_size'],
+                           self.cfg['image_size'], out=self.out, chunk=self.chunk,
+                           hm_buf=self.hm.view(-1))
 
     def parts(self, steps):
         """(kernel ms, repack ms) per step and kernel launches per step: HIP events around
