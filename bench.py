@@ -55,12 +55,15 @@ def parse():
     ap.add_argument('--backward', action='store_true',
                     help='also time the training step (forward with clamp mask + backward + '
                          'un-repack) and report it beside the headline')
-    ap.add_argument('--chunk', type=int, default=8,
+    ap.add_argument('--chunk', type=int, default=None,
                     help='root workload: frames per repack+unproject chunk (one reused '
                          'channel-last buffer that stays in the Infinity Cache)')
     ap.add_argument('--window-chunk', type=int, default=None,
                     help='window workloads: frames per chunk (default: cache-sized, about 40 '
                          'windows per launch)')
+    ap.add_argument('--channels', type=int, default=None,
+                    help='heatmap channels instead of the config\'s joint count (TEMPO\'s own '
+                         'configs unproject 32 learned features)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     return ap.parse_args()
 
@@ -71,6 +74,12 @@ def make_inputs(args, dev, seed, cfg=None):
     from tempo_amd import synthetic as S
     from tempo_amd.camera import pack_cameras
     cfg = S.PANOPTIC if cfg is None else cfg
+    if getattr(args, 'channels', None):
+        import copy
+        h36m = cfg is S.H36M
+        cfg = copy.deepcopy(cfg)
+        cfg['num_joints'] = args.channels
+        cfg['_h36m'] = h36m
     B, V, J = args.batch, cfg['num_views'], cfg['num_joints']
     w, h = cfg['heatmap_size']
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -78,7 +87,7 @@ def make_inputs(args, dev, seed, cfg=None):
     ncal = max(1, min(args.calibrations, B))
     centers, scales, cameras = [], [], []
     for k in range(ncal):
-        cams = (S.h36m_cameras() if cfg is S.H36M else
+        cams = (S.h36m_cameras() if (cfg is S.H36M or cfg.get('_h36m')) else
                 S.ring_cameras(V, seed=seed + 1000 * k, target=cfg['space_center']))
         nb = (B * (k + 1)) // ncal - (B * k) // ncal
         c, s, m = S.frame_meta(cams, nb, cfg['raw_size'], cfg['image_size'])
@@ -111,7 +120,8 @@ class RootWorkload:
         cp = ops.padded_channels(self.J)
         # frames go through in chunks that reuse one channel-last buffer (ops.root_step);
         # the grouped launch works on the whole batch
-        self.chunk = self.B if self.groups is not None else min(args.chunk, self.B)
+        auto = ops.chunk_frames(self.V, h, w, cp)
+        self.chunk = self.B if self.groups is not None else min(args.chunk or auto, self.B)
         self.hm = torch.empty(self.chunk, self.V, h, w, cp, device=dev)
         self.out = torch.empty(self.B, self.J, X, Y, Z, device=dev)
         self.samples = self.B * self.N * self.V
@@ -418,7 +428,7 @@ def measured_traffic(args, wl):
     tag = 'root' if args.workload == 'root' else ('planes' if args.planes == 'only' else 'window')
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01',
                         tag + '_pmc_summary.csv')
-    if (args.batch != 32 or (tag != 'root' and args.proposals != 10) or args.chunk != 8
+    if (args.batch != 32 or (tag != 'root' and args.proposals != 10) or args.chunk not in (None, 8) or args.channels
             or not os.path.exists(path)):
         return None, None
     vals = {}
