@@ -479,15 +479,9 @@ def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
     return out, grids, mask
 
 
-def unproject_window(hm, cam, fine_axes, tl, start, end, sub_cube, channels,
-                     heatmap_size, image_size, win_frame=None, live=None, out=None,
-                     mm_mode='auto', groups=None, clamp_mask=None):
-    """Per-person window unprojection.  hm ``[F,V,H,W,CP]``, cam ``[F,V,32]``,
-    tl/start/end int32 ``[NW,3]``, win_frame int32 ``[NW]`` or None (NW == F).
-    ``groups``: device int32 ``[NG,2]``, runs of consecutive windows with equal
-    tl/start/end whose frames have equal camera records (the T timesteps of one
-    proposal).  Returns cubes ``[NW,C,VX,VY,VZ]``."""
-    lib = _lib.load()
+def _window_args(hm, cam, fine_axes, tl, start, end, sub_cube, channels, win_frame, live):
+    """Checks shared by the window entry points; returns
+    ``(device, hm.shape, fine axes, NW, (VX, VY, VZ), C)``."""
     dev = hm.device
     _need(hm, torch.float32, 'hm')
     F_, V, H, W, CP = hm.shape
@@ -510,8 +504,20 @@ def unproject_window(hm, cam, fine_axes, tl, start, end, sub_cube, channels,
         _need(live, torch.uint8, 'live', dev)
         if live.numel() != NW:
             raise ValueError('live must have one entry per window')
-    VX, VY, VZ = (int(v) for v in sub_cube)
-    C = int(channels)
+    return dev, (F_, V, H, W, CP), fa, NW, tuple(int(v) for v in sub_cube), int(channels)
+
+
+def unproject_window(hm, cam, fine_axes, tl, start, end, sub_cube, channels,
+                     heatmap_size, image_size, win_frame=None, live=None, out=None,
+                     mm_mode='auto', groups=None, clamp_mask=None):
+    """Per-person window unprojection.  hm ``[F,V,H,W,CP]``, cam ``[F,V,32]``,
+    tl/start/end int32 ``[NW,3]``, win_frame int32 ``[NW]`` or None (NW == F).
+    ``groups``: device int32 ``[NG,2]``, runs of consecutive windows with equal
+    tl/start/end whose frames have equal camera records (the T timesteps of one
+    proposal).  Returns cubes ``[NW,C,VX,VY,VZ]``."""
+    lib = _lib.load()
+    dev, (F_, V, H, W, CP), fa, NW, (VX, VY, VZ), C = _window_args(
+        hm, cam, fine_axes, tl, start, end, sub_cube, channels, win_frame, live)
     if out is None:
         out = torch.empty(NW, C, VX, VY, VZ, dtype=torch.float32, device=dev)
     else:
@@ -552,30 +558,8 @@ def unproject_window_planes(hm, cam, fine_axes, tl, start, end, sub_cube, channe
     plane_yz [NW,C,VY,VZ])`` = ``torch.max`` of the volume over z, y, x; with
     ``want_cubes=False`` the volume is never written."""
     lib = _lib.load()
-    dev = hm.device
-    _need(hm, torch.float32, 'hm')
-    F_, V, H, W, CP = hm.shape
-    _need(cam, torch.float32, 'cam', dev)
-    if tuple(cam.shape) != (F_, V, 32):
-        raise ValueError(f'cam must be [{F_},{V},32], got {tuple(cam.shape)}')
-    fa = [_need(a, torch.float32, 'fine_axes', dev) for a in fine_axes]
-    NW = int(tl.shape[0])
-    for name, t in (('tl', tl), ('start', start), ('end', end)):
-        _need(t, torch.int32, name, dev)
-        if tuple(t.shape) != (NW, 3):
-            raise ValueError(f'{name} must be [{NW},3]')
-    if win_frame is not None:
-        _need(win_frame, torch.int32, 'win_frame', dev)
-        if win_frame.numel() != NW:
-            raise ValueError('win_frame must have one entry per window')
-    elif NW != F_:
-        raise ValueError('without win_frame there must be one window per frame')
-    if live is not None:
-        _need(live, torch.uint8, 'live', dev)
-        if live.numel() != NW:
-            raise ValueError('live must have one entry per window')
-    VX, VY, VZ = (int(v) for v in sub_cube)
-    C = int(channels)
+    dev, (F_, V, H, W, CP), fa, NW, (VX, VY, VZ), C = _window_args(
+        hm, cam, fine_axes, tl, start, end, sub_cube, channels, win_frame, live)
     cubes = None
     if want_cubes:
         cubes = out if out is not None else torch.empty(NW, C, VX, VY, VZ,
