@@ -409,7 +409,9 @@ class ProjectLayerWithMask(nn.Module):
             grid[0, :, :, 1:].reshape(-1, 2)
         ]).to(device)
 
-    def get_voxel(self, feature_maps, grid_center, centers, scales, cameras):
+    def _window_inputs(self, feature_maps, grid_center, centers, scales, cameras):
+        """Per-call constants of the window kernels: integer window geometry
+        (``project_layer.py:299-324``), skip flags (``:232``), packed cameras."""
         device = _check_inputs(feature_maps)
         B, C = feature_maps[0].shape[:2]
         if grid_center.device != device:
@@ -421,7 +423,12 @@ class ProjectLayerWithMask(nn.Module):
             live = (grid_center[:, 3] >= 0).to(torch.uint8).contiguous()
         cam = pack_cameras(centers, scales, cameras, self.image_size,
                            self.mm_mode).to(device)
-        tl, st, en = (t.to(torch.int32).contiguous() for t in (centers_tl, start, end))
+        geo = tuple(t.to(torch.int32).contiguous() for t in (centers_tl, start, end))
+        return device, B, C, offset, live, cam, geo
+
+    def get_voxel(self, feature_maps, grid_center, centers, scales, cameras):
+        device, B, C, offset, live, cam, (tl, st, en) = self._window_inputs(
+            feature_maps, grid_center, centers, scales, cameras)
         if _wants_grad(feature_maps):  # training: differentiable path
             meta = dict(kind='window', cam=cam, fine_axes=self._fine_axes, tl=tl, start=st,
                         end=en, sub_cube=list(self._sub_cube), live=live,
@@ -447,21 +454,11 @@ class ProjectLayerWithMask(nn.Module):
         Returns ``(plane_xy [B,C,X,Y], plane_xz [B,C,X,Z], plane_yz [B,C,Y,Z], offset,
         cubes | None)``; with ``want_cubes=False`` the ``[B,C,X,Y,Z]`` volume is never
         written to memory."""
-        device = _check_inputs(feature_maps)
         if _wants_grad(feature_maps):
             raise NotImplementedError(
                 'get_planes is forward-only; use forward() + torch.max for training')
-        B, C = feature_maps[0].shape[:2]
-        if grid_center.device != device:
-            grid_center = grid_center.to(device)
-        centers_tl, offset, start, end = self.window_geometry(grid_center)
-        self._ensure_grids(device)
-        live = None
-        if grid_center.shape[1] != 3:
-            live = (grid_center[:, 3] >= 0).to(torch.uint8).contiguous()
-        cam = pack_cameras(centers, scales, cameras, self.image_size,
-                           self.mm_mode).to(device)
-        tl, st, en = (t.to(torch.int32).contiguous() for t in (centers_tl, start, end))
+        device, B, C, offset, live, cam, (tl, st, en) = self._window_inputs(
+            feature_maps, grid_center, centers, scales, cameras)
         vx, vy, vz = self._sub_cube
         cubes = (torch.empty(B, C, vx, vy, vz, dtype=torch.float32, device=device)
                  if want_cubes else None)
