@@ -312,22 +312,8 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
   // phase A of one view: project this lane's voxel, park (4 offsets, 4 weights)
   // in LDS buffer `buf`.  Returns false when no lane of the wave needs the view
   // (nothing written then).
-#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 6  // projection of view 0 reused by every view
-  u32x4 abl_off = {0, 0, 0, 0};
-  float4 abl_wt = make_float4(0.f, 0.f, 0.f, 0.f);
-  bool abl_act = false;
-#endif
   auto phase_a = [&](int slot, int buf) -> bool {
     const int view = slot_view(a, slot);
-#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 6
-    if (slot > 0) {
-      if (abl_act) {
-        s_off[buf * kWaveVox + lane] = abl_off;
-        s_wt[buf * kWaveVox + lane] = abl_wt;
-      }
-      return abl_act;
-    }
-#endif
     const TempoCam cam = load_cam(a.cam, frame * a.V + view);
     TempoPix p;
     p.px = p.py = 0.f;
@@ -373,14 +359,7 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
 #endif
       s_off[buf * kWaveVox + lane] = off;
       s_wt[buf * kWaveVox + lane] = wt;
-#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 6
-      abl_off = off;
-      abl_wt = wt;
-#endif
     }
-#if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 6
-    abl_act = active;
-#endif
     return active;
   };
 
@@ -702,20 +681,17 @@ __global__ __launch_bounds__(kPlaneWaves * 64) void unproject_planes_kernel(
       for (int ch = 0; ch < a.C; ch++) dst[(long long)ch * a.N] = s_out[ch * TSTR + lane];
     }
     const int xs = (x - x_begin) % kPlaneXB;
-#ifndef TEMPO_PL_ABL
-#define TEMPO_PL_ABL 0
-#endif
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
       if ((ch & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // four rows in flight, not CH
       const unsigned v = __float_as_uint(s_out[ch * TSTR + lane]);
       over_x[ch] = v > over_x[ch] ? v : over_x[ch];
-      if (v != 0u && !(TEMPO_PL_ABL & 1))
+      if (v != 0u)
         __hip_atomic_fetch_max(acc + (xs * CH + ch) * kWaveVox + lane, v, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (a.pl01 != nullptr && !(TEMPO_PL_ABL & 2)) {
+    if (a.pl01 != nullptr) {
       // max over z: four lanes per channel row of the tile, 16 voxels each, then
       // the quad is combined (16 channels per pass)
 #pragma unroll
@@ -739,7 +715,7 @@ __global__ __launch_bounds__(kPlaneWaves * 64) void unproject_planes_kernel(
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if ((xs == kPlaneXB - 1 || x == x_end - 1) && !(TEMPO_PL_ABL & 1)) {
+    if (xs == kPlaneXB - 1 || x == x_end - 1) {
       __syncthreads();
       for (int r = wave; r < (xs + 1) * CH; r += kPlaneWaves) {
         const int rx = r / CH, ch = r - rx * CH;
