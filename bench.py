@@ -438,7 +438,11 @@ def measured_traffic(args, wl):
                 vals[row['counter']] = float(row['mean_per_dispatch'])
     if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
         return None, None
-    return int((vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), 'profiles/r01/' + tag + '_pmc_summary.csv'
+    src = 'profiles/r01/' + tag + '_pmc_summary.csv'
+    if 'TCC_HIT_sum' in vals and 'TCC_MISS_sum' in vals:  # L2 hit rate of the same passes
+        measured_traffic.l2_hit = round(
+            vals['TCC_HIT_sum'] / (vals['TCC_HIT_sum'] + vals['TCC_MISS_sum']), 4)
+    return int((vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), src
 
 
 def main():
@@ -609,6 +613,7 @@ def main():
                 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'traffic_source': traffic_src,
+                'l2_hit_rate': getattr(measured_traffic, 'l2_hit', None),
                 'kernel': wl.kernel_name, 'kernel_ms': round(k_ms, 4),
                 'launches_per_step': launches,
                 'kernel_launch_ms': round(k_ms / launches, 4),
