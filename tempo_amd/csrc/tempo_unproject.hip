@@ -1304,7 +1304,9 @@ int launch_one(const UnprojArgs& a, hipStream_t stream) {
   // sub-steps whose fetches are in flight together (8 = all of a view's)
   // (wider texels: two sub-steps keep the fetch registers at 32 and the occupancy up;
   // 20 channels 0.38 -> 0.31 ms, 32 channels 0.53 -> 0.49 ms at config 2's shape)
-  constexpr int SB = MODE == MODE_ROOT ? (L == 4 ? TEMPO_SB_ROOT : 2) : TEMPO_SB_WINDOW;
+  // (window, 28-32 channels: two sub-steps, 8.07 -> 7.58 ms at config 3's shape)
+  constexpr int SB = MODE == MODE_ROOT ? (L == 4 ? TEMPO_SB_ROOT : 2)
+                                       : (L >= 7 ? 2 : TEMPO_SB_WINDOW);
   UnprojArgs k = a;
   for (int i = 0; i < 2; i++) {
     const unsigned long long m = 0x100000000ULL / (unsigned)a.dim[2 - i];
