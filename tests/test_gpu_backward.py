@@ -157,3 +157,53 @@ def test_backward_is_linear_and_matches_directional_derivative(gpu_device):
     lhs = float(((plus - here) * w1)[finite].sum())
     rhs = float(sum((a * e).sum() for a, e in zip(g1, d)))
     assert abs(lhs - rhs) <= 2e-3 * max(1.0, abs(rhs))
+
+
+def test_more_than_32_channels_goes_through_slices(gpu_device):
+    """40 channels = two kernel calls (32 + 8) on every path: forward, z-max, planes,
+    backward -- against the oracle and autograd through it."""
+    import tempo_amd
+    # root
+    spec = dict(cases.ROOT_CASES['root_panoptic_small'], num_joints=40, seed=77)
+    case = cases.build_root(None, full=spec)
+    args = list(case['args'])
+    ref_fms = _leafs(args[0])
+    ref_layer = O.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, _ = ref_layer(ref_fms, *args[1:])
+    g = torch.Generator().manual_seed(11)
+    weight = torch.randn(ref_cubes.shape, generator=g)
+    (ref_cubes * weight).sum().backward()
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    layer.keep_zmax = True
+    fms = _leafs(args[0], gpu_device)
+    with torch.no_grad():
+        plain, _ = layer([f.detach() for f in fms], *args[1:])
+    assert float((plain.cpu() - ref_cubes.detach()).abs().max()) <= 1e-5
+    assert torch.equal(layer.last_zmax, plain.max(dim=4)[0])
+    cubes, _ = layer(fms, *args[1:])
+    assert torch.equal(cubes.detach(), plain)
+    (cubes * weight.to(gpu_device)).sum().backward()
+    _grads_close([f.grad for f in fms], [f.grad for f in ref_fms], 'root 40 channels')
+    # window
+    spec = dict(cases.WINDOW_CASES['win_panoptic_small'], num_joints=40, seed=78)
+    case = cases.build_window(None, full=spec)
+    args = list(case['args'])
+    ref_fms = _leafs(args[0])
+    ref_layer = O.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, _ = ref_layer(ref_fms, *args[1:])
+    weight = torch.randn(ref_cubes.shape, generator=g)
+    (ref_cubes * weight).sum().backward()
+    layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    fms = _leafs(args[0], gpu_device)
+    gc = args[1].to(gpu_device)
+    with torch.no_grad():
+        plain, _ = layer([f.detach() for f in fms], gc, *args[2:])
+        pxy, pxz, pyz, _, vol = layer.get_planes([f.detach() for f in fms], gc, *args[6:],
+                                                 want_cubes=True)
+    assert float((plain.cpu() - ref_cubes.detach()).abs().max()) <= 1e-5
+    assert torch.equal(vol, plain)
+    for p, dim in ((pxy, 4), (pxz, 3), (pyz, 2)):
+        assert torch.equal(p, plain.max(dim=dim)[0])
+    cubes, _ = layer(fms, gc, *args[2:])
+    (cubes * weight.to(gpu_device)).sum().backward()
+    _grads_close([f.grad for f in fms], [f.grad for f in ref_fms], 'window 40 channels')
