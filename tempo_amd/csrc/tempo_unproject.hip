@@ -41,6 +41,10 @@ namespace {
 #define TEMPO_SB_WINDOW 1
 #endif
 constexpr int kThreads = 256;
+#ifndef TEMPO_TILE_WAVES
+#define TEMPO_TILE_WAVES 4
+#endif
+constexpr int kTileWaves = TEMPO_TILE_WAVES;  // waves per workgroup of the tile kernel
 constexpr int kWaveVox = 64;                // voxels per wave
 // LDS bytes per wave: 2 x 64 records of 32 B while gathering, then the [CP][65]
 // output tile
@@ -589,7 +593,7 @@ __device__ __forceinline__ void unproject_block(const UnprojArgs& a, int bid,
 }
 
 template <int MODE, int L, int SB, int UNF>
-__global__ __launch_bounds__(kThreads) void unproject_kernel(const UnprojArgs a) {
+__global__ __launch_bounds__(kTileWaves * 64) void unproject_kernel(const UnprojArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   unproject_block<MODE, L, SB, UNF>(a, blockIdx.x, smem);
 }
@@ -1344,12 +1348,14 @@ int launch_one(const UnprojArgs& a, hipStream_t stream) {
                        dim3(kThreads), (size_t)waves * k.wave_lds, stream, k);
     return (int)hipGetLastError();
   }
+  k.tile_vox = kTileWaves * kWaveVox;
+  k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
   const long long total = (long long)a.NB * k.tiles;
   if (total > 0x7fffffffLL / 8) return TEMPO_E_DIM;
   k.total = (int)total;
   k.chunk = (k.total + 7) / 8;
   hipLaunchKernelGGL((unproject_kernel<MODE, L, SB, UNF>), dim3(8 * k.chunk),
-                     dim3(kThreads), (size_t)waves * wave_lds_bytes(L), stream, k);
+                     dim3(kTileWaves * 64), (size_t)kTileWaves * wave_lds_bytes(L), stream, k);
   return (int)hipGetLastError();
 }
 
