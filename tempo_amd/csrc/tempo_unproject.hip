@@ -1165,6 +1165,243 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
   }
 }
 
+// ------------------------------------------- window backward, pre-aggregated
+// The fine lattice's voxels are one to a few heatmap pixels apart, so the
+// four-texel footprints of neighbouring voxels overlap and the per-sample
+// scatter above sends several atomics to every texel it touches; the L2 retires
+// about one atomic lane per clock and channel, which is what bounds that kernel.
+// Here one wave (= one workgroup) owns a brick of 4 x 4 x 4 voxels and, per
+// view, sums the brick's footprints into a wave-private LDS tile of TE x TE
+// texels anchored at the brick's smallest (x0, y0), then flushes the tile with
+// one global atomic per touched (texel, channel).
+// LDS float atomics are no faster than the L2's (measured: 0.55 lanes per clock
+// and CU), so the tile is accumulated with plain read-add-write: one voxel per
+// step, lane = (texel of the footprint, channel), so the lanes of an instruction
+// never collide and the LDS executes a wave's accesses in order.
+// A footprint box larger than the tile (a near camera) is retried as the
+// brick's two halves; a half that still does not fit goes to memory directly,
+// as above: the tile is an accelerator, never a correctness condition.
+// TE = 10 measured best on config 3 (8: 31.8 ms, 10: 26.6, 12: 29.8 -- a larger
+// tile fits more views but leaves fewer waves per CU); per-sample kernel: 108.9.
+constexpr int kBrickEdge = 4;
+#ifndef TEMPO_BRICK_TILE
+#define TEMPO_BRICK_TILE 10
+#endif
+constexpr int kBrickTile = TEMPO_BRICK_TILE;  // TE
+struct BrickLds {
+  int tile, stage, off, wt, total;
+};
+constexpr BrickLds brick_lds(int L) {
+  BrickLds l{};
+  l.tile = 0;
+  l.stage = kBrickTile * kBrickTile * 4 * L * 4;
+  l.off = l.stage + 4 * L * (kWaveVox + 1) * 4;
+  l.wt = l.off + 4 * kWaveVox * 4;
+  l.total = l.wt + 4 * kWaveVox * 4;
+  return l;
+}
+
+template <int L, int UNF>
+__global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojArgs a) {
+  constexpr int MODE = MODE_WINDOW;
+  constexpr int VPS = 64 / L;
+  constexpr int CP = 4 * L;
+  constexpr int TSTR = kWaveVox + 1;
+  constexpr int TE = kBrickTile;
+  constexpr BrickLds LD = brick_lds(L);
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* tile = reinterpret_cast<float*>(smem + LD.tile);  // [TE][TE][CP]
+  float* st = reinterpret_cast<float*>(smem + LD.stage);   // [CP][TSTR]
+  int* s_off = reinterpret_cast<int*>(smem + LD.off);      // [4][64]
+  float* s_wt = reinterpret_cast<float*>(smem + LD.wt);    // [4][64]
+
+  const int bid = blockIdx.x;
+  const int run = bid >> 3;
+  const int item = (bid & 7) * a.chunk + run;
+  if (run >= a.chunk || item >= a.total) return;
+  const int b = __builtin_amdgcn_readfirstlane(item / a.tiles);
+  const int lane = threadIdx.x;
+  int frame = b;
+  if (a.win_frame != nullptr) frame = uniform_load(a.win_frame, b);
+  if ((a.live != nullptr && uniform_load_u8(a.live, b) == 0) || (unsigned)frame >= (unsigned)a.F)
+    return;  // a skipped item's volume is constant zero: no gradient
+
+  const int nb1 = (a.dim[1] + kBrickEdge - 1) / kBrickEdge;
+  const int nb2 = (a.dim[2] + kBrickEdge - 1) / kBrickEdge;
+  const int brick = item - b * a.tiles;
+  const int bx = __builtin_amdgcn_readfirstlane(brick / (nb1 * nb2));
+  const int by = __builtin_amdgcn_readfirstlane((brick - bx * nb1 * nb2) / nb2);
+  const int bz = brick - (bx * nb1 + by) * nb2;
+  const int i0 = bx * kBrickEdge + (lane >> 4);
+  const int i1 = by * kBrickEdge + ((lane >> 2) & 3);
+  const int i2 = bz * kBrickEdge + (lane & 3);
+  const bool inb = i0 < a.dim[0] && i1 < a.dim[1] && i2 < a.dim[2];
+  const int n = (i0 * a.dim[1] + i1) * a.dim[2] + i2;
+
+  // incoming gradient (lane = voxel), divided by the view count and zeroed where
+  // the forward's clamp blocks it, parked as [channel][voxel]
+  {
+    const float* gout = a.cubes + (long long)b * a.C * a.N;
+    const float den = (float)a.V + 1e-6f;
+    // the forward's mask layout: tile n >> 6, word [s * 4 + j], bit vq * L + cq
+    // for voxel s * VPS + vq of the tile and channel 4 cq + j
+    const int vs = n & 63, s = vs / VPS, vq = vs - s * VPS;
+    const unsigned long long* mw =
+        a.cmask + ((long long)b * ((a.N + kWaveVox - 1) / kWaveVox) + (n >> 6)) * mask_words(L) +
+        s * 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const unsigned long long word = inb ? mw[j] : 0ull;
+#pragma unroll
+      for (int cq = 0; cq < L; cq++) {
+        // (the load is unconditional so that the CP loads of a lane overlap)
+        const int ch = 4 * cq + j;
+        const bool open = inb && ch < a.C && ((word >> (vq * L + cq)) & 1ull);
+        const float g = gout[(long long)(ch < a.C ? ch : 0) * a.N + (inb ? n : 0)];
+        st[ch * TSTR + lane] = open ? g / den : 0.0f;
+      }
+    }
+  }
+  for (int i = lane; i < TE * TE * CP; i += 64) tile[i] = 0.0f;
+  float x = 0.f, y = 0.f, z = 0.f;
+  const bool have = inb && voxel_world<MODE>(a, b, n, &x, &y, &z);
+  if (__builtin_amdgcn_ballot_w64(have) == 0) return;
+
+  // step layout: TP footprint texels x CP channels per instruction
+  constexpr int TP = 64 / CP >= 4 ? 4 : 64 / CP;
+  constexpr int NP = (4 + TP - 1) / TP;
+  const int tq = lane / CP;
+  const int c = lane - tq * CP;
+
+#pragma unroll 1
+  for (int slot = 0; slot < a.V; slot++) {
+    const int view = slot_view(a, slot);
+    const TempoCam cam = load_cam(a.cam, frame * a.V + view);
+    float* vbase = a.ghm + (long long)frame * a.frame_stride +
+                   (long long)view * (a.view_bytes / 4);
+    TempoPix p;
+    p.px = p.py = 0.f;
+    p.inside = 0;
+    if (have) p = tempo_world_to_pixel(&cam, x, y, z, UNF);
+    float gx, gy, fw, fn;
+    int x0, y0;
+    tempo_pixel_to_grid(&cam, p.px, p.py, &a.geom, UNF, &gx, &gy);
+    tempo_bilinear_frac(gx, gy, a.W, a.H, &x0, &y0, &fw, &fn);
+    // a NaN sample point adds nothing (grid_sampler's backward finds none of its
+    // texels inside the map)
+    const bool ok = have && gx == gx && gy == gy;
+    const bool cx[2] = {ok && (unsigned)x0 < (unsigned)a.W, ok && (unsigned)(x0 + 1) < (unsigned)a.W};
+    const bool ry[2] = {(unsigned)y0 < (unsigned)a.H, (unsigned)(y0 + 1) < (unsigned)a.H};
+    const bool on = (cx[0] || cx[1]) && (ry[0] || ry[1]);
+    const float e = 1.0f - fw, sth = 1.0f - fn;
+    const float wt[4] = {sth * e, sth * fw, fn * e, fn * fw};
+    // the whole brick first; if its footprint box is larger than the tile, the
+    // brick's two halves (2 x 4 x 4 voxels = 32 lanes) one after the other
+    int parts = 1;
+#pragma unroll 1
+    for (int part = 0; part < parts; part++) {
+      const bool sel = on && (parts == 1 || (lane >> 5) == part);
+      // footprint box (|x0|, |y0| < 2^15: host-checked map size, and the sample
+      // grid is clamped to +-1.1)
+      const unsigned k0 = wave_umax_to_lane63(sel ? (unsigned)(32767 - x0) : 0u);
+      const unsigned k1 = wave_umax_to_lane63(sel ? (unsigned)(32767 - y0) : 0u);
+      const unsigned k2 = wave_umax_to_lane63(sel ? (unsigned)(x0 + 32768) : 0u);
+      const unsigned k3 = wave_umax_to_lane63(sel ? (unsigned)(y0 + 32768) : 0u);
+      const unsigned o2 = (unsigned)__builtin_amdgcn_readlane((int)k2, 63);
+      if (o2 == 0u) continue;  // no voxel of this part projects into the view
+      const int ox = 32767 - __builtin_amdgcn_readlane((int)k0, 63);
+      const int oy = 32767 - __builtin_amdgcn_readlane((int)k1, 63);
+      const int bw = (int)o2 - 32768 + 2 - ox;
+      const int bh = __builtin_amdgcn_readlane((int)k3, 63) - 32768 + 2 - oy;
+      const bool fits = bw <= TE && bh <= TE;  // wave-uniform
+      if (!fits && parts == 1) {
+        parts = 2;
+        part = -1;
+        continue;
+      }
+      const int kbeg = parts == 1 ? 0 : part * 32, kend = parts == 1 ? kWaveVox : kbeg + 32;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const bool valid = sel && cx[t & 1] && ry[t >> 1];
+        const int gxx = x0 + (t & 1), gyy = y0 + (t >> 1);
+        const int o = fits ? ((gyy - oy) * TE + (gxx - ox)) * CP : (gyy * a.W + gxx) * CP;
+        s_off[t * kWaveVox + lane] = valid ? o : -1;
+        s_wt[t * kWaveVox + lane] = wt[t];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+      if (!fits) {
+        // still too large (a camera much closer than usual): straight to memory,
+        // as in unproject_backward_kernel
+        constexpr int VP2 = 64 / CP;  // voxels per step, CP adjacent lanes = one texel's channels
+#pragma unroll 4
+        for (int v0 = kbeg; v0 < kend; v0 += VP2) {
+          const int vsl = v0 + tq;
+          if (!(tq < VP2 && vsl < kend)) continue;
+          const float g = st[c * TSTR + vsl];
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const int o = s_off[t * kWaveVox + vsl];
+            if (o < 0) continue;
+            const float v = g * s_wt[t * kWaveVox + vsl];
+            if (v != 0.0f) unsafeAtomicAdd(vbase + o + c, v);
+          }
+        }
+      } else {
+        // accumulate: one voxel per step; operands of KB voxels are read ahead of
+        // their read-add-write chain
+        constexpr int KB = 8;
+#pragma unroll 1
+        for (int k0v = kbeg; k0v < kend; k0v += KB) {
+          int of[KB][NP];
+          float pv[KB][NP];
+#pragma unroll
+          for (int kk = 0; kk < KB; kk++) {
+            const float g = st[c * TSTR + k0v + kk];
+#pragma unroll
+            for (int pp = 0; pp < NP; pp++) {
+              const int t = pp * TP + tq;
+              const bool lane_on = tq < TP && t < 4;
+              of[kk][pp] = lane_on ? s_off[t * kWaveVox + k0v + kk] : -1;
+              pv[kk][pp] = lane_on ? g * s_wt[t * kWaveVox + k0v + kk] : 0.0f;
+            }
+          }
+#pragma unroll
+          for (int kk = 0; kk < KB; kk++) {
+#pragma unroll
+            for (int pp = 0; pp < NP; pp++) {
+              if (of[kk][pp] >= 0) tile[of[kk][pp] + c] += pv[kk][pp];
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        // flush (and clear) the part of the tile the footprint box reaches
+        for (int ty = 0; ty < bh; ty++) {
+          const int gyy = oy + ty;
+          if ((unsigned)gyy >= (unsigned)a.H) continue;  // (nothing was added there)
+          float* trow = tile + ty * TE * CP;
+          float* grow = vbase + ((long long)gyy * a.W + ox) * CP;
+          for (int i = lane; i < bw * CP; i += 64) {
+            const float v = trow[i];
+            if (v != 0.0f) {
+              trow[i] = 0.0f;
+              unsafeAtomicAdd(grow + i, v);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
 // channel-last [B][V][HW][CP] -> per-view NCHW slices (inverse of the repack),
 // 64-pixel tiles
 struct UnrepackArgs {
@@ -1385,9 +1622,54 @@ int launch_backward_one(const UnprojArgs& a, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
+// window backward through the LDS tile (window_backward_brick_kernel)
+template <int L, int UNF>
+int launch_backward_brick(const UnprojArgs& a, hipStream_t stream) {
+  UnprojArgs k = a;
+  for (int i = 0; i < 2; i++) {
+    const unsigned long long m = 0x100000000ULL / (unsigned)a.dim[2 - i];
+    k.magic[i] = m > 0xffffffffULL ? 0xffffffffu : (unsigned)m;
+  }
+  for (int w = 0; w < 10; w++) k.order[w] = 0xffffffffu;
+  for (int sl = 0; sl < a.V; sl++) {
+    const unsigned v = (unsigned)tempo_view_of_slot(sl, a.V);
+    k.order[sl >> 2] = (k.order[sl >> 2] & ~(255u << ((sl & 3) * 8))) | (v << ((sl & 3) * 8));
+  }
+  const long long bricks = (long long)((a.dim[0] + kBrickEdge - 1) / kBrickEdge) *
+                           ((a.dim[1] + kBrickEdge - 1) / kBrickEdge) *
+                           ((a.dim[2] + kBrickEdge - 1) / kBrickEdge);
+  const long long total = (long long)a.NB * bricks;
+  if (total > 0x7fffffffLL / 8) return TEMPO_E_DIM;
+  k.tile_vox = kWaveVox;
+  k.tiles = (int)bricks;
+  k.total = (int)total;
+  k.chunk = (k.total + 7) / 8;
+  hipLaunchKernelGGL((window_backward_brick_kernel<L, UNF>), dim3(8 * k.chunk), dim3(64),
+                     (size_t)brick_lds(L).total, stream, k);
+  return (int)hipGetLastError();
+}
+
 template <int MODE>
 int launch_backward(const UnprojArgs& a, int mm_unfused, hipStream_t stream) {
   if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
+#ifndef TEMPO_NO_BRICK
+  // the footprint box is kept in 16-bit texel coordinates
+  if (MODE == MODE_WINDOW && a.W <= 16384 && a.H <= 16384) {
+#define TEMPO_BRICK_CASE(LL)                                      \
+  case LL:                                                        \
+    return mm_unfused ? launch_backward_brick<LL, 1>(a, stream)   \
+                      : launch_backward_brick<LL, 0>(a, stream);
+    switch (a.CP / 4) {
+      TEMPO_BRICK_CASE(4)
+      TEMPO_BRICK_CASE(5)
+      TEMPO_BRICK_CASE(6)
+      TEMPO_BRICK_CASE(7)
+      TEMPO_BRICK_CASE(8)
+      default: return TEMPO_E_PAD;
+    }
+#undef TEMPO_BRICK_CASE
+  }
+#endif
 #define TEMPO_BWD_CASE(LL)                                          \
   case LL:                                                          \
     return mm_unfused ? launch_backward_one<MODE, LL, 1>(a, stream) \

@@ -80,6 +80,34 @@ def test_window_backward_vs_autograd(name, gpu_device):
     _grads_close([f.grad for f in fms], ref_grads, name)
 
 
+@pytest.mark.parametrize('sub_mm,cube', [(400, 16), (560, 14), (800, 16)])
+def test_window_backward_fine_lattices(sub_mm, cube, gpu_device):
+    """The window backward sums each 4x4x4 brick's footprints in an LDS tile before
+    touching memory when the brick's footprint box fits the tile, retries the brick
+    as two halves when it does not, and falls back to per-sample atomics last.
+    Lattices of 25, 40 and 50 mm (the small cases above are 62-100 mm) reach all
+    three; values outside [0,1] put both sides of the clamp mask into it, and a
+    14^3 window leaves partial bricks on every axis."""
+    import tempo_amd
+    spec = dict(cases.WINDOW_CASES['win_panoptic_small'], sub=[sub_mm] * 3,
+                sub_cube=[cube] * 3, seed=300 + cube + sub_mm, hm='noise')
+    case = cases.build_window(None, full=spec)
+    args = list(case['args'])
+    base = [f * 3.0 - 1.0 for f in args[0]]
+    ref_fms = _leafs(base)
+    ref_layer = O.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, _ = ref_layer(ref_fms, *args[1:])
+    g = torch.Generator().manual_seed(9)
+    weight = torch.randn(ref_cubes.shape, generator=g)
+    (ref_cubes * weight).sum().backward()
+    layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    fms = _leafs(base, gpu_device)
+    cubes, _ = layer(fms, args[1].to(gpu_device), *args[2:])
+    assert float((cubes.detach().cpu() - ref_cubes.detach()).abs().max()) <= 1e-5
+    (cubes * weight.to(gpu_device)).sum().backward()
+    _grads_close([f.grad for f in fms], [f.grad for f in ref_fms], f'window {sub_mm} mm / {cube}^3')
+
+
 def test_backward_with_negative_and_saturated_values(gpu_device):
     """Feature maps outside [0,1] exercise both sides of the clamp mask."""
     import tempo_amd
