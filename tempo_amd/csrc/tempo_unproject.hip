@@ -1518,6 +1518,56 @@ void launch_repack_wide(const RepackArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL((repack_wide_kernel<L>), grid, dim3(kThreads), 0, stream, a);
 }
 
+// The inverse with the same tile: 256 * CP * 4 contiguous bytes in (16-byte
+// loads, transposed b32 writes into the channel-major LDS tile), 1 KB runs of one
+// channel plane out.  Same conditions as the wide repack.
+template <int L>
+__global__ __launch_bounds__(kThreads) void unrepack_wide_kernel(const UnrepackArgs a) {
+  __shared__ __attribute__((aligned(16))) float s[4 * L * kWideStr];
+  const int p0 = blockIdx.x * kWidePix;
+  const int v = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float4* in = reinterpret_cast<const float4*>(
+      a.in + (((long long)b * a.V + v) * a.HW + p0) * (4 * L));
+  float4 r[L];
+#pragma unroll
+  for (int j = 0; j < L; j++) {
+    const int i = tid + kThreads * j;
+    r[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (p0 + i / L < a.HW) r[j] = in[i];
+  }
+#pragma unroll
+  for (int j = 0; j < L; j++) {
+    const int i = tid + kThreads * j;
+    const int px = i / L, cq = i - px * L;
+    float* col = s + 4 * cq * kWideStr + px;
+    col[0] = r[j].x;
+    col[kWideStr] = r[j].y;
+    col[2 * kWideStr] = r[j].z;
+    col[3 * kWideStr] = r[j].w;
+  }
+  __syncthreads();
+  float* out = a.views[v] + ((long long)b * a.C_total + a.c_begin) * a.HW;
+  const int p = p0 + 4 * lane;
+#pragma unroll
+  for (int k = 0; k < L; k++) {
+    const int c = wave + 4 * k;
+    if (c < a.C && p < a.HW) {
+      const float* row = s + c * kWideStr + 4 * lane;
+      const float2 lo = *reinterpret_cast<const float2*>(row);
+      const float2 hi = *reinterpret_cast<const float2*>(row + 2);
+      *reinterpret_cast<float4*>(out + (long long)c * a.HW + p) =
+          make_float4(lo.x, lo.y, hi.x, hi.y);
+    }
+  }
+}
+
+template <int L>
+void launch_unrepack_wide(const UnrepackArgs& a, hipStream_t stream) {
+  dim3 grid((a.HW + kWidePix - 1) / kWidePix, a.V, a.B);
+  hipLaunchKernelGGL((unrepack_wide_kernel<L>), grid, dim3(kThreads), 0, stream, a);
+}
+
 // ---------------------------------------------------------- project points
 __global__ __launch_bounds__(kThreads) void project_points_kernel(
     const float* __restrict__ pts, const float* __restrict__ cam, int N,
@@ -1924,8 +1974,23 @@ int tempo_unrepack_nchw(const float* in, void* const* views, int V, int B, int C
   a.in = in;
   a.V = V; a.B = B; a.C_total = C_total; a.c_begin = c_begin; a.C = C;
   a.HW = H * W; a.CP = CP;
-  dim3 grid((a.HW + 63) / 64, V, B);
-  hipLaunchKernelGGL(unrepack_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+  bool wide = a.HW % 4 == 0 && (((long long)C_total * a.HW) % 4 == 0) &&
+              (((long long)c_begin * a.HW) % 4 == 0) &&
+              reinterpret_cast<uintptr_t>(in) % 16 == 0;
+  for (int v = 0; v < V; v++) wide = wide && (reinterpret_cast<uintptr_t>(views[v]) % 16 == 0);
+  if (wide) {
+    switch (CP / 4) {
+      case 4: launch_unrepack_wide<4>(a, (hipStream_t)stream); break;
+      case 5: launch_unrepack_wide<5>(a, (hipStream_t)stream); break;
+      case 6: launch_unrepack_wide<6>(a, (hipStream_t)stream); break;
+      case 7: launch_unrepack_wide<7>(a, (hipStream_t)stream); break;
+      case 8: launch_unrepack_wide<8>(a, (hipStream_t)stream); break;
+      default: return TEMPO_E_PAD;
+    }
+  } else {
+    dim3 grid((a.HW + 63) / 64, V, B);
+    hipLaunchKernelGGL(unrepack_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+  }
   return (int)hipGetLastError();
 }
 

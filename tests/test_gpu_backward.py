@@ -130,7 +130,11 @@ def test_backward_with_negative_and_saturated_values(gpu_device):
 def test_unrepack_inverts_repack(gpu_device):
     from tempo_amd import ops
     torch.manual_seed(9)
-    for (B, V, C, H, W) in ((2, 3, 15, 7, 37), (1, 2, 17, 16, 64), (2, 2, 32, 5, 13)):
+    # HW % 4 != 0 takes the 64-pixel kernel, the others the 256-pixel one (whole tiles, a
+    # partial last tile, fewer pixels than one tile; 16 to 32 padded channels)
+    for (B, V, C, H, W) in ((2, 3, 15, 7, 37), (1, 2, 17, 16, 64), (2, 2, 32, 5, 13),
+                            (2, 2, 15, 6, 50), (1, 3, 20, 128, 240), (1, 2, 29, 12, 20),
+                            (3, 1, 24, 3, 4)):
         fms = [torch.rand(B, C, H, W, device=gpu_device) for _ in range(V)]
         back = ops.unrepack_nchw(ops.repack_nhwc(fms), C)
         for a, b in zip(fms, back):
