@@ -108,6 +108,28 @@ def test_window_backward_fine_lattices(sub_mm, cube, gpu_device):
     _grads_close([f.grad for f in fms], [f.grad for f in ref_fms], f'window {sub_mm} mm / {cube}^3')
 
 
+def test_window_backward_on_maps_wider_than_the_tile_coordinates(gpu_device):
+    """The LDS-tile kernel keeps footprint boxes in 16-bit texel coordinates; maps wider or
+    taller than 16384 texels take the per-sample kernel instead. Same bar."""
+    import tempo_amd
+    spec = dict(cases.WINDOW_CASES['win_panoptic_small'], B=2, hm_size=[16400, 8],
+                img_size=[16400, 8], seed=411, hm='noise')
+    case = cases.build_window(None, full=spec)
+    args = list(case['args'])
+    ref_fms = _leafs(args[0])
+    ref_layer = O.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, _ = ref_layer(ref_fms, *args[1:])
+    g = torch.Generator().manual_seed(10)
+    weight = torch.randn(ref_cubes.shape, generator=g)
+    (ref_cubes * weight).sum().backward()
+    layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    fms = _leafs(args[0], gpu_device)
+    cubes, _ = layer(fms, args[1].to(gpu_device), *args[2:])
+    assert float((cubes.detach().cpu() - ref_cubes.detach()).abs().max()) <= 1e-5
+    (cubes * weight.to(gpu_device)).sum().backward()
+    _grads_close([f.grad for f in fms], [f.grad for f in ref_fms], 'window, 16400-texel rows')
+
+
 def test_backward_with_negative_and_saturated_values(gpu_device):
     """Feature maps outside [0,1] exercise both sides of the clamp mask."""
     import tempo_amd
