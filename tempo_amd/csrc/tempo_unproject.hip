@@ -1171,9 +1171,10 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
 // scatter above sends several atomics to every texel it touches; the L2 retires
 // about one atomic lane per clock and channel, which is what bounds that kernel.
 // Here one wave (= one workgroup) owns a brick of 4 x 4 x 4 voxels and, per
-// view, sums the brick's footprints into a wave-private LDS tile of TE x TE
-// texels anchored at the brick's smallest (x0, y0), then flushes the tile with
-// one global atomic per touched (texel, channel).
+// view, sums the brick's footprints into a wave-private LDS tile anchored at the
+// brick's smallest (x0, y0), then flushes the tile with one global atomic per
+// touched (texel, channel).  The tile holds kBrickCap texels in rows of the
+// footprint box's own width, so any box of at most that area fits.
 // LDS float atomics are no faster than the L2's (measured: 0.55 lanes per clock
 // and CU), so the tile is accumulated with plain read-add-write: one voxel per
 // step, lane = (texel of the footprint, channel), so the lanes of an instruction
@@ -1181,23 +1182,23 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
 // A footprint box larger than the tile (a near camera) is retried as the
 // brick's two halves; a half that still does not fit goes to memory directly,
 // as above: the tile is an accelerator, never a correctness condition.
-// TE = 10 measured best on config 3 (8: 31.8 ms, 10: 26.6, 12: 29.8 -- a larger
-// tile fits more views but leaves fewer waves per CU); per-sample kernel: 108.9.
+// Config 3, ms per launch: 108.9 per-sample kernel; square 10 x 10 tile 26.9; box-shaped
+// rows 24.2; 81 texels (14 waves per CU) 22.6; 12-byte voxel records (16 waves) 21.0.
 constexpr int kBrickEdge = 4;
-#ifndef TEMPO_BRICK_TILE
-#define TEMPO_BRICK_TILE 10
+#ifndef TEMPO_BRICK_CAP
+#define TEMPO_BRICK_CAP 81
 #endif
-constexpr int kBrickTile = TEMPO_BRICK_TILE;  // TE
+constexpr int kBrickCap = TEMPO_BRICK_CAP;  // texels per tile
 struct BrickLds {
-  int tile, stage, off, wt, total;
+  int tile, stage, rec, total;
 };
+// CP = 16: 81 * 64 + 16 * 65 * 4 + 64 * 12 = 10112 bytes, 16 waves per CU
 constexpr BrickLds brick_lds(int L) {
   BrickLds l{};
   l.tile = 0;
-  l.stage = kBrickTile * kBrickTile * 4 * L * 4;
-  l.off = l.stage + 4 * L * (kWaveVox + 1) * 4;
-  l.wt = l.off + 4 * kWaveVox * 4;
-  l.total = l.wt + 4 * kWaveVox * 4;
+  l.stage = kBrickCap * 4 * L * 4;
+  l.rec = l.stage + 4 * L * (kWaveVox + 1) * 4;
+  l.total = l.rec + 3 * kWaveVox * 4;
   return l;
 }
 
@@ -1207,13 +1208,17 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
   constexpr int VPS = 64 / L;
   constexpr int CP = 4 * L;
   constexpr int TSTR = kWaveVox + 1;
-  constexpr int TE = kBrickTile;
+  constexpr int CAP = kBrickCap;
   constexpr BrickLds LD = brick_lds(L);
   extern __shared__ __align__(16) unsigned char smem[];
-  float* tile = reinterpret_cast<float*>(smem + LD.tile);  // [TE][TE][CP]
+  float* tile = reinterpret_cast<float*>(smem + LD.tile);  // CAP texels x CP
   float* st = reinterpret_cast<float*>(smem + LD.stage);   // [CP][TSTR]
-  int* s_off = reinterpret_cast<int*>(smem + LD.off);      // [4][64]
-  float* s_wt = reinterpret_cast<float*>(smem + LD.wt);    // [4][64]
+  // per voxel and view: 16 * (index of the footprint's top-left texel, in the tile or in
+  // the map) + four bits saying which of its four texels are inside the map, and the two
+  // bilinear fractions
+  int* s_base = reinterpret_cast<int*>(smem + LD.rec);  // [64]
+  float* s_fw = reinterpret_cast<float*>(smem + LD.rec) + kWaveVox;
+  float* s_fn = s_fw + kWaveVox;
 
   const int bid = blockIdx.x;
   const int run = bid >> 3;
@@ -1262,7 +1267,7 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
       }
     }
   }
-  for (int i = lane; i < TE * TE * CP; i += 64) tile[i] = 0.0f;
+  for (int i = lane; i < CAP * CP; i += 64) tile[i] = 0.0f;
   float x = 0.f, y = 0.f, z = 0.f;
   const bool have = inb && voxel_world<MODE>(a, b, n, &x, &y, &z);
   if (__builtin_amdgcn_ballot_w64(have) == 0) return;
@@ -1293,8 +1298,8 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
     const bool cx[2] = {ok && (unsigned)x0 < (unsigned)a.W, ok && (unsigned)(x0 + 1) < (unsigned)a.W};
     const bool ry[2] = {(unsigned)y0 < (unsigned)a.H, (unsigned)(y0 + 1) < (unsigned)a.H};
     const bool on = (cx[0] || cx[1]) && (ry[0] || ry[1]);
-    const float e = 1.0f - fw, sth = 1.0f - fn;
-    const float wt[4] = {sth * e, sth * fw, fn * e, fn * fw};
+    const unsigned inmap = (cx[0] && ry[0] ? 1u : 0u) | (cx[1] && ry[0] ? 2u : 0u) |
+                           (cx[0] && ry[1] ? 4u : 0u) | (cx[1] && ry[1] ? 8u : 0u);
     // the whole brick first; if its footprint box is larger than the tile, the
     // brick's two halves (2 x 4 x 4 voxels = 32 lanes) one after the other
     int parts = 1;
@@ -1313,20 +1318,34 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
       const int oy = 32767 - __builtin_amdgcn_readlane((int)k1, 63);
       const int bw = (int)o2 - 32768 + 2 - ox;
       const int bh = __builtin_amdgcn_readlane((int)k3, 63) - 32768 + 2 - oy;
-      const bool fits = bw <= TE && bh <= TE;  // wave-uniform
+      // the tile holds CAP texels in rows of the box's own width, so any box of at
+      // most that area fits (oblique views give long, thin boxes)
+      const bool fits = bw <= CAP && bh <= CAP && bw * bh <= CAP;  // wave-uniform
       if (!fits && parts == 1) {
         parts = 2;
         part = -1;
         continue;
       }
       const int kbeg = parts == 1 ? 0 : part * 32, kend = parts == 1 ? kWaveVox : kbeg + 32;
+      // texel (x0 + i, y0 + j) sits at (base + i + j * stride) * CP, in the tile or in
+      // the gradient map; its weight is (j ? fn : 1 - fn) * (i ? fw : 1 - fw)
+      const int stride = fits ? bw : a.W;
+      const int base = fits ? (y0 - oy) * bw + (x0 - ox) : y0 * a.W + x0;
+      s_base[lane] = base * 16 + (int)(sel ? inmap : 0u);
+      s_fw[lane] = fw;
+      s_fn[lane] = fn;
+      int toff[NP];
+      float sx[NP], ax[NP], sy[NP], ay[NP];
+      unsigned tbit[NP];
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        const bool valid = sel && cx[t & 1] && ry[t >> 1];
-        const int gxx = x0 + (t & 1), gyy = y0 + (t >> 1);
-        const int o = fits ? ((gyy - oy) * TE + (gxx - ox)) * CP : (gyy * a.W + gxx) * CP;
-        s_off[t * kWaveVox + lane] = valid ? o : -1;
-        s_wt[t * kWaveVox + lane] = wt[t];
+      for (int pp = 0; pp < NP; pp++) {
+        const int t = pp * TP + tq;
+        toff[pp] = ((t & 1) + (t >> 1) * stride) * CP + c;
+        tbit[pp] = (tq < TP && t < 4) ? 1u << t : 0u;
+        sx[pp] = (t & 1) ? 1.0f : -1.0f;  // fma(fw, sx, ax) = fw or 1 - fw, exactly
+        ax[pp] = (t & 1) ? 0.0f : 1.0f;
+        sy[pp] = (t >> 1) ? 1.0f : -1.0f;
+        ay[pp] = (t >> 1) ? 0.0f : 1.0f;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -1341,12 +1360,15 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
           const int vsl = v0 + tq;
           if (!(tq < VP2 && vsl < kend)) continue;
           const float g = st[c * TSTR + vsl];
+          const int bs = s_base[vsl];
+          const float vw = s_fw[vsl], vn = s_fn[vsl];
 #pragma unroll
           for (int t = 0; t < 4; t++) {
-            const int o = s_off[t * kWaveVox + vsl];
-            if (o < 0) continue;
-            const float v = g * s_wt[t * kWaveVox + vsl];
-            if (v != 0.0f) unsafeAtomicAdd(vbase + o + c, v);
+            if (!((bs >> t) & 1)) continue;
+            const float wgt = ((t >> 1) ? vn : 1.0f - vn) * ((t & 1) ? vw : 1.0f - vw);
+            const float v = g * wgt;
+            if (v != 0.0f)
+              unsafeAtomicAdd(vbase + ((bs >> 4) + (t & 1) + (t >> 1) * stride) * CP + c, v);
           }
         }
       } else {
@@ -1360,19 +1382,19 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
 #pragma unroll
           for (int kk = 0; kk < KB; kk++) {
             const float g = st[c * TSTR + k0v + kk];
+            const int bs = s_base[k0v + kk];
+            const float vw = s_fw[k0v + kk], vn = s_fn[k0v + kk];
 #pragma unroll
             for (int pp = 0; pp < NP; pp++) {
-              const int t = pp * TP + tq;
-              const bool lane_on = tq < TP && t < 4;
-              of[kk][pp] = lane_on ? s_off[t * kWaveVox + k0v + kk] : -1;
-              pv[kk][pp] = lane_on ? g * s_wt[t * kWaveVox + k0v + kk] : 0.0f;
+              of[kk][pp] = ((unsigned)bs & tbit[pp]) ? (bs >> 4) * CP + toff[pp] : -1;
+              pv[kk][pp] = g * (fmaf(vn, sy[pp], ay[pp]) * fmaf(vw, sx[pp], ax[pp]));
             }
           }
 #pragma unroll
           for (int kk = 0; kk < KB; kk++) {
 #pragma unroll
             for (int pp = 0; pp < NP; pp++) {
-              if (of[kk][pp] >= 0) tile[of[kk][pp] + c] += pv[kk][pp];
+              if (of[kk][pp] >= 0) tile[of[kk][pp]] += pv[kk][pp];
             }
           }
         }
@@ -1384,7 +1406,7 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
         for (int ty = 0; ty < bh; ty++) {
           const int gyy = oy + ty;
           if ((unsigned)gyy >= (unsigned)a.H) continue;  // (nothing was added there)
-          float* trow = tile + ty * TE * CP;
+          float* trow = tile + ty * bw * CP;
           float* grow = vbase + ((long long)gyy * a.W + ox) * CP;
           for (int i = lane; i < bw * CP; i += 64) {
             const float v = trow[i];
