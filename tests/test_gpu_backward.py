@@ -108,6 +108,28 @@ def test_window_backward_fine_lattices(sub_mm, cube, gpu_device):
     _grads_close([f.grad for f in fms], [f.grad for f in ref_fms], f'window {sub_mm} mm / {cube}^3')
 
 
+@pytest.mark.parametrize('joints', [22, 27])
+def test_window_backward_other_channel_widths(joints, gpu_device):
+    """24 and 28 padded channels: two footprint texels per accumulate step instead of four
+    (15, 17 and 32 channels are covered by the cases above)."""
+    import tempo_amd
+    spec = dict(cases.WINDOW_CASES['win_panoptic_small'], B=2, num_joints=joints,
+                sub=[500] * 3, seed=500 + joints, hm='noise')
+    case = cases.build_window(None, full=spec)
+    args = list(case['args'])
+    ref_fms = _leafs(args[0])
+    ref_layer = O.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, _ = ref_layer(ref_fms, *args[1:])
+    g = torch.Generator().manual_seed(11)
+    weight = torch.randn(ref_cubes.shape, generator=g)
+    (ref_cubes * weight).sum().backward()
+    layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    fms = _leafs(args[0], gpu_device)
+    cubes, _ = layer(fms, args[1].to(gpu_device), *args[2:])
+    (cubes * weight.to(gpu_device)).sum().backward()
+    _grads_close([f.grad for f in fms], [f.grad for f in ref_fms], f'window, {joints} channels')
+
+
 def test_window_backward_on_maps_wider_than_the_tile_coordinates(gpu_device):
     """The LDS-tile kernel keeps footprint boxes in 16-bit texel coordinates; maps wider or
     taller than 16384 texels take the per-sample kernel instead. Same bar."""
