@@ -1183,7 +1183,8 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
 // brick's two halves; a half that still does not fit goes to memory directly,
 // as above: the tile is an accelerator, never a correctness condition.
 // Config 3, ms per launch: 108.9 per-sample kernel; square 10 x 10 tile 26.9; box-shaped
-// rows 24.2; 81 texels (14 waves per CU) 22.6; 12-byte voxel records (16 waves) 21.0.
+// rows 24.2; 81 texels (14 waves per CU) 22.6; 12-byte voxel records (16 waves) 21.0;
+// gradient loads issued together 20.2.
 constexpr int kBrickEdge = 4;
 #ifndef TEMPO_BRICK_CAP
 #define TEMPO_BRICK_CAP 81
@@ -1250,21 +1251,24 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
     const float den = (float)a.V + 1e-6f;
     // the forward's mask layout: tile n >> 6, word [s * 4 + j], bit vq * L + cq
     // for voxel s * VPS + vq of the tile and channel 4 cq + j
-    const int vs = n & 63, s = vs / VPS, vq = vs - s * VPS;
+    const int nn = inb ? n : 0;  // lanes outside the volume read voxel 0 and drop it
+    const int vs = nn & 63, s = vs / VPS, vq = vs - s * VPS;
     const unsigned long long* mw =
-        a.cmask + ((long long)b * ((a.N + kWaveVox - 1) / kWaveVox) + (n >> 6)) * mask_words(L) +
+        a.cmask + ((long long)b * ((a.N + kWaveVox - 1) / kWaveVox) + (nn >> 6)) * mask_words(L) +
         s * 4;
+    // all CP + 4 loads first (unconditional), so that they overlap
+    unsigned long long word[4];
+    float gv[CP];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const unsigned long long word = inb ? mw[j] : 0ull;
+    for (int j = 0; j < 4; j++) word[j] = mw[j];
 #pragma unroll
-      for (int cq = 0; cq < L; cq++) {
-        // (the load is unconditional so that the CP loads of a lane overlap)
-        const int ch = 4 * cq + j;
-        const bool open = inb && ch < a.C && ((word >> (vq * L + cq)) & 1ull);
-        const float g = gout[(long long)(ch < a.C ? ch : 0) * a.N + (inb ? n : 0)];
-        st[ch * TSTR + lane] = open ? g / den : 0.0f;
-      }
+    for (int ch = 0; ch < CP; ch++) gv[ch] = gout[(long long)(ch < a.C ? ch : 0) * a.N + nn];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ch = 0; ch < CP; ch++) {
+      const int cq = ch >> 2, j = ch & 3;
+      const bool open = inb && ch < a.C && ((word[j] >> (vq * L + cq)) & 1ull);
+      st[ch * TSTR + lane] = open ? gv[ch] / den : 0.0f;
     }
   }
   for (int i = lane; i < CAP * CP; i += 64) tile[i] = 0.0f;
