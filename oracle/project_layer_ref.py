@@ -21,13 +21,21 @@ dd3c49418730e2d3651ff62fe04fb4319168c7c1 / 0.28.1 by ``setup.sh:9-13`` and
 * ``mmpose...post_transforms.affine_transform_torch`` call sites ``:117,:258``
 * ``mmpose.models.utils.misc.torch_meshgrid_ij``      call sites ``:55,:215``
 
-Their published algorithms are restated below.  PARITY UNPINNED: the reference
-ships no tests, golden vectors or fixtures for this path
-and the module cannot be imported here (mmcv/mmpose/cv2 missing -- an ordinary
-ModuleNotFoundError, nothing was denied), so this restatement could only be
-checked against the reference's source text, against torch's own
-``F.grid_sample`` (which it calls, exactly like the reference) and against an
-independent float64 evaluation of the same formulas (tests/test_oracle.py).
+Their published algorithms are restated below.
+
+PARITY, what is pinned and what is not.  ``tests/golden/check_against_reference.py``
+(build container) loads the reference's own ``tempo/models/project_layer.py``
+with these restated helpers standing in for the absent mmcv/mmpose imports and
+asserts that THIS file equals it bit for bit (cubes, grids, valid-view mask,
+offset, fine_grid, center_grid, scale, bias) on every case of tests/cases.py and
+on BASELINE configs 1 and 3 at full size; ``tests/golden/*.npz`` hold the
+reference module's outputs.  That pins everything restated from
+``project_layer.py``.  The four helpers themselves (rows
+a7-a9: mmpose camera model, cv2 affine solve) are the same code on both sides of
+that check and stay PARITY UNPINNED: the reference ships no vectors for them and
+mmpose/cv2 cannot be installed here; they are checked against the reference's
+call sites, mmpose's published formulas and an independent float64 evaluation
+(tests/test_oracle.py).
 
 The code keeps the reference's structure on purpose (python loop over batch and
 views, one ``grid_sample`` per view, the ``[B,C,1,N,V]`` intermediate, masked

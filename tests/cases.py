@@ -1,5 +1,5 @@
 """Seeded test cases shared by the CPU tests, the GPU parity tests and
-tests/golden/make_golden.py.  Inputs are always regenerated from the seed;
+tests/golden/check_against_reference.py.  Inputs are always regenerated from the seed;
 golden files hold only expected outputs (plus input checksums)."""
 import copy
 
