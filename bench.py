@@ -10,15 +10,25 @@ heatmap tensors + the unprojection kernel, through the C ABI.  Inputs (heatmaps,
 packed camera table, grid axes) are resident in HBM before the timed region.
 One sample = one (voxel, view) pair producing all J channel values: B*N*V.
 
-With N > 1 ranks (launched by torch.distributed.run) every rank processes its own
-32 frames (frames x proposals partition, no data-path collective): weak scaling;
-value = samples of all ranks / max-over-ranks time.
+With N > 1 every rank processes its own 32 frames (frames x proposals partition, no
+data-path collective): weak scaling; value = samples of all ranks / max-over-ranks time.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself:
+the parent, which never touches the GPU, runs `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` as a child process (what the reference's
+tools/dist_train.sh:12-20 does with torch.distributed.launch) and relays rank 0's line.
+When the driver has already launched the ranks (WORLD_SIZE set) nothing is spawned.
+
+The timed region is `--blocks` blocks (default 5) of exactly `--steps` steps, each
+bracketed by barrier + synchronize; the MEDIAN block (max over ranks within a block) is
+reported -- one block of the default 50 steps lasts only ~15 ms.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,7 +40,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -65,7 +75,14 @@ def parse():
                     help='heatmap channels instead of the config\'s joint count (TEMPO\'s own '
                          'configs unproject 32 learned features)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    return ap.parse_args()
+    ap.add_argument('--blocks', type=int, default=5,
+                    help='timed blocks of --steps steps each; the median block is reported')
+    ap.add_argument('--dry-run', action='store_true',
+                    help='no GPU: ranks rendezvous over gloo and run an empty workload '
+                         '(exercises the launcher and the timing protocol on a CPU box)')
+    ap.add_argument('--no-module', action='store_true',
+                    help='skip the module-level (drop-in nn.Module.forward) timing')
+    return ap.parse_args(argv)
 
 
 def make_inputs(args, dev, seed, cfg=None):
@@ -95,6 +112,7 @@ def make_inputs(args, dev, seed, cfg=None):
         scales += s
         cameras += m
     cam_host = pack_cameras(centers, scales, cameras, cfg['image_size'])
+    make_inputs.meta = (centers, scales, cameras)  # the lists of dicts the module is called with
     return cfg, fms, cam_host.to(dev), cam_host
 
 
@@ -105,6 +123,7 @@ class RootWorkload:
         from tempo_amd import ops, project_layer as PL
         self.ops = ops
         self.cfg, self.fms, self.cam, cam_host = make_inputs(args, dev, seed)
+        self.meta = make_inputs.meta
         cfg = self.cfg
         self.B, self.V, self.J = args.batch, cfg['num_views'], cfg['num_joints']
         # frames with bit-identical camera records share one projection per voxel
@@ -185,6 +204,7 @@ class WindowWorkload:
         from tempo_amd import ops, project_layer as PL, synthetic as S
         self.ops = ops
         self.cfg, self.fms, self.cam, _ = make_inputs(args, dev, seed, getattr(S, self.cfg_src))
+        self.meta = make_inputs.meta
         cfg = self.cfg
         self.B, self.V, self.J = args.batch, cfg['num_views'], cfg['num_joints']
         P = args.proposals
@@ -200,6 +220,7 @@ class WindowWorkload:
                                  invalid_every=0, margin=0.15).to(dev)
         props[:, 5:7] = 1.0  # full windows: every voxel is sampled
         props = props.repeat_interleave(T, 0)
+        self.props = props
         tl, _, st, en = layer.window_geometry(props)
         layer._ensure_grids(dev)
         self.geo = [t.to(torch.int32).contiguous() for t in (tl, st, en)]
@@ -445,40 +466,168 @@ def measured_traffic(args, wl):
     return int((vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), src
 
 
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args):
+    """--gpus N > 1 outside a torch.distributed launch: start the N ranks as a child
+    process group (one process per GPU) and exit with its code.  The parent has not
+    touched the GPU and replaces nothing: it waits for the child."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.run(cmd, env=env).returncode
+
+
+class DryWorkload:
+    """--dry-run: no device work at all; what is left is the launcher, the rendezvous
+    and the block timing protocol (CPU boxes, tests/test_bench_launcher.py)."""
+    name = 'dry_run'
+    B, V, J, samples, kernel_bytes, kernel_name = 0, 0, 0, 0, 0, 'none'
+
+    def step(self):
+        time.sleep(0.001)
+
+
+def oracle_check(args, wl, dev):
+    """max-abs error of one item of the timed output against the CPU oracle run on the
+    same inputs (item 0: a whole frame of the root grid / the first window)."""
+    from oracle import project_layer_ref as O
+    cfg = wl.cfg
+    centers, scales, cameras = wl.meta
+    fms = [f[0:1].cpu() for f in wl.fms]
+    one = ([centers[0]], [scales[0]], [cameras[0]])
+    if args.workload in ('root', 'dense'):
+        if args.workload == 'dense' and getattr(wl, 'world', 1) > 1:
+            return None
+        layer = O.ProjectLayer(cfg['image_size'], cfg['heatmap_size'], 'mean')
+        ref, _ = layer(fms, cfg['space_size'], [cfg['space_center']], cfg['cube_size'], *one)
+        got = wl.out[0:1].cpu()
+        what = 'frame 0 of the timed output vs oracle ProjectLayer on the same inputs'
+    else:
+        if wl.out is None:
+            return None
+        layer = O.ProjectLayerWithMask(cfg['image_size'], cfg['heatmap_size'], 'mean')
+        ref, _ = layer(fms, wl.props[0:1].cpu(), cfg['space_center'], cfg['space_size'],
+                       cfg['sub_space_size'], cfg['sub_cube_size'], *one)
+        got = wl.out[0:1].cpu()
+        what = 'window 0 of the timed output vs oracle ProjectLayerWithMask on the same inputs'
+    same_nan = bool(torch.equal(got.isnan(), ref.isnan()))
+    err = float((torch.nan_to_num(got) - torch.nan_to_num(ref)).abs().max())
+    return {'max_abs_err': err, 'nan_positions_equal': same_nan,
+            'differing_elements': int((torch.nan_to_num(got) != torch.nan_to_num(ref)).sum()),
+            'elements': ref.numel(), 'what': what}
+
+
+def module_timing(args, wl, dev):
+    """The drop-in nn.Module called the way tempo_detector.py:187-190 calls it: lists of V
+    [B,C,H,W] tensors and lists of per-(frame, view) dicts, B = 32.  First call (cold
+    caches: camera packing, axes) and steady state (median of 20), host-synchronised wall
+    time -- what a caller of the module sees, host packing included."""
+    import tempo_amd
+    cfg = wl.cfg
+    centers, scales, cameras = wl.meta
+    layer = tempo_amd.ProjectLayer(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    layer.materialize_grids = False  # the caller drops `grids` (tempo_detector.py:187)
+    call = lambda: layer(wl.fms, cfg['space_size'], [cfg['space_center']], cfg['cube_size'],
+                         centers, scales, cameras)
+    times = []
+    with torch.no_grad():
+        for _ in range(23):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cubes, _ = call()
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) * 1e3)
+    same = bool(torch.equal(torch.nan_to_num(cubes, nan=-1.0),
+                            torch.nan_to_num(wl.out, nan=-1.0)))
+    steady = sorted(times[3:])
+    return {'first_call_ms': round(times[0], 3), 'steady_ms': round(steady[len(steady) // 2], 4),
+            'equals_timed_output': same,
+            'what': 'tempo_amd.ProjectLayer.forward(list of [B,C,H,W], ..., lists of dicts), '
+                    'host-synchronised wall time incl. camera packing; grids not materialised'}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))  # before anything touches the GPU
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a HIP device (tempo_amd has no CPU path)')
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
     dist = None
+    if args.dry_run:
+        dev = torch.device('cpu')
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs a HIP device (tempo_amd has no CPU path)')
+        torch.cuda.set_device(local)
+        dev = torch.device('cuda', local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if args.dry_run:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
-    wl = make_workload(args, dev, seed=rank)
+    def sync():
+        if not args.dry_run:
+            torch.cuda.synchronize()
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local])
-        torch.cuda.synchronize()
+            if args.dry_run:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local])
+        sync()
+
+    # ranks the collective library actually connected (an all-reduce of ones)
+    seen = 1
+    if dist is not None:
+        one = torch.ones(1, device=dev, dtype=torch.float32)
+        dist.all_reduce(one)
+        seen = int(round(float(one.item())))
+
+    wl = DryWorkload() if args.dry_run else make_workload(args, dev, seed=rank)
 
     for _ in range(args.warmup):
         wl.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    block_s = []
+    for _ in range(max(1, args.blocks)):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            wl.step()
+        barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        block_s.append(el)
+    elapsed = sorted(block_s)[len(block_s) // 2]
+
+    if args.dry_run:
+        if rank == 0:
+            print(json.dumps({'metric': 'voxel-view heatmap samples/sec', 'value': 0.0,
+                              'unit': 'Gsamp/s', 'n_gpus': seen, 'steps': args.steps,
+                              'warmup': args.warmup,
+                              'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+                              'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+                              'dtype': 'f32', 'data': 'none', 'dry_run': True,
+                              'config': {'workload': 'dry_run', 'ranks_launched': world}}),
+                  flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     # dominant kernel alone, HIP events on the launch stream
     if hasattr(wl, 'parts'):
@@ -499,6 +648,26 @@ def main():
         k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
         r_ms = sum(c.elapsed_time(d) for c, d in rp) / len(rp)
         launches = 1
+    comm_ms = None
+    if args.workload == 'dense' and world > 1:  # the all-gather + permute alone
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        e0.record()
+        for _ in range(args.steps):
+            wl.full = wl.parallel.gather_z_slabs(wl.out)
+        e1.record()
+        torch.cuda.synchronize()
+        comm_ms = e0.elapsed_time(e1) / args.steps
+
+    # parity of what was just timed, and the module-level cost of the same call
+    check = module = None
+    if rank == 0 and world == 1:
+        wl.step()
+        torch.cuda.synchronize()
+        check = oracle_check(args, wl, dev)
+        if args.workload == 'root' and not args.no_module and wl.groups is None \
+                and not args.channels:
+            module = module_timing(args, wl, dev)
 
     # fused epilogue: what the reference's caller does instead (tempo_pose.py:172-176) --
     # the volume kernel followed by torch.max over each axis, on the same inputs
@@ -590,11 +759,12 @@ def main():
         traffic, traffic_src = measured_traffic(args, wl)
         ms_step = elapsed / args.steps * 1e3
         achieved = wl.kernel_bytes / (k_ms * 1e-3) / 1e9
+        step_achieved = wl.kernel_bytes / (ms_step * 1e-3) / 1e9
         line = {
             'metric': 'voxel-view heatmap samples/sec',
             'value': round(wl.samples * world / (elapsed / args.steps) / 1e9, 4),
             'unit': 'Gsamp/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': seen, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(ms_step, 4),
             'higher_is_better': True, 'scaling': getattr(wl, 'scaling', 'weak'),
             'vs_baseline': None,
@@ -606,13 +776,22 @@ def main():
                        'planes': getattr(wl, 'planes_mode', 'off'),
                        'views': wl.V,
                        'joints': wl.J, 'samples_per_step_per_gpu': wl.samples,
+                       'input_layout': getattr(wl, 'input_layout', 'nchw'),
+                       'ranks_launched': world,
                        'partition': (f'z-slabs over {world} rank(s), one all-gather'
                                      if args.workload == 'dense' else
                                      f'frames x proposals over {world} rank(s), no collective')},
+            'timing': {'blocks': len(block_s), 'steps_per_block': args.steps,
+                       'block_ms_per_step': [round(b / args.steps * 1e3, 4) for b in block_s],
+                       'reported': 'median block, max over ranks within a block'},
             'roofline': {
+                # `bound` names the yardstick (SURVEY 8d prices the path by HBM bytes);
+                # `limiter` says what the kernel actually waits on
                 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'traffic_source': traffic_src,
+                'step_frac': round(step_achieved / HBM_PEAK_GBS, 4),
+                'limiter': getattr(wl, 'limiter', None),
                 'l2_hit_rate': getattr(measured_traffic, 'l2_hit', None),
                 'kernel': wl.kernel_name, 'kernel_ms': round(k_ms, 4),
                 'launches_per_step': launches,
@@ -622,6 +801,12 @@ def main():
             'repack_ms': round(r_ms, 4),
             'kernel_gsamp_s': round(wl.samples / (k_ms * 1e-3) / 1e9, 3),
         }
+        if comm_ms is not None:
+            line['allgather_ms'] = round(comm_ms, 4)
+        if check is not None:
+            line['oracle_check'] = check
+        if module is not None:
+            line['module_ms'] = module
         if unfused is not None:
             line['unfused_consumer'] = unfused
         if train is not None:

@@ -14,6 +14,9 @@
  *    > 0 = a hipError_t from the launch.  Nothing throws or exits;
  *  - re-entrant: no mutable globals; concurrent calls on different streams
  *    are safe as long as their output buffers do not overlap;
+ *  - heatmap buffers in channel-last layout (hm, grad_hm, the repack's out, the
+ *    root step's workspace) must be 16-byte aligned: they are accessed with
+ *    128-bit loads and stores (TEMPO_E_ARG otherwise);
  *  - all floating point is IEEE fp32; the operation order of the per-voxel
  *    arithmetic is fixed (tempo_amd/csrc/unproject_math.h) so that results do
  *    not depend on the launch shape.
@@ -44,7 +47,7 @@
 extern "C" {
 #endif
 
-#define TEMPO_ABI_VERSION 4
+#define TEMPO_ABI_VERSION 5
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
@@ -255,8 +258,12 @@ int tempo_unproject_window_train(const float* hm, const float* cam,
  *                then accumulated with fp32 atomics (windows of one frame add
  *                up), so sums agree with autograd to rounding, not bit for bit.
  *                tempo_unrepack_nchw turns it into per-view NCHW gradients.
- * All other arguments as in the forward calls.  At most 12 views (TEMPO_E_DIM
- * beyond: the per-view footprints of a tile are kept in LDS). */
+ * All other arguments as in the forward calls.  Any number of views up to
+ * TEMPO_MAX_VIEWS: the root backward (and the window backward for maps wider or
+ * taller than 16384 texels) keeps the per-view footprints of a tile in LDS, 11
+ * views per launch at CP = 16 (10 at 20, 9 at 24, 8 at 28, 7 at 32); more views go
+ * through in several launches on `stream`.  The default window backward keeps no
+ * per-view records. */
 int tempo_unproject_root_backward(const float* grad_cubes, const float* cam,
                                   const float* ax_x, const float* ax_y,
                                   const float* ax_z, int ax_batched,

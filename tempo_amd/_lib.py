@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TEMPO_LIB') or os.path.join(_HERE, 'lib', 'libtempo_unproject.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_void_p, _c_int, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 

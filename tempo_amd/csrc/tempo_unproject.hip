@@ -101,6 +101,7 @@ struct UnprojArgs {
   const int32_t* groups;  // grouped launch: [NG][2] = (first item, count), or nullptr
   int NG;
   int wave_lds;  // grouped launch: LDS bytes per wave
+  int slot0, slot1;  // root / per-sample backward: slots [slot0, slot1) are scattered by this launch
   unsigned order[10];  // slot -> view in torch's summation order (one byte per slot, 255 = empty)
   unsigned magic[2];   // floor(2^32 / dim[2]), floor(2^32 / dim[1]): voxel index -> (i0, i1, i2)
 };
@@ -203,7 +204,8 @@ __device__ __forceinline__ void planes_epilogue(const UnprojArgs& a, int b, int 
   const int before = __shfl_up(col, 1);
   const bool head = lane == 0 || before != col;
   for (int ch = 0; ch < a.C; ch++) {
-    const unsigned v = on ? __float_as_uint(s_out[ch * tstr + lane]) : 0u;
+    unsigned v = on ? __float_as_uint(s_out[ch * tstr + lane]) : 0u;
+    v = v == 0x80000000u ? 0u : v;  // -0.0 (a clamped negative underflow) orders as +0.0
     if (v != 0u) {
       if (a.pl02 != nullptr)
         __hip_atomic_fetch_max(a.pl02 + ((bc + ch) * a.dim[0] + i0) * a.dim[2] + i2, v,
@@ -688,7 +690,8 @@ __global__ __launch_bounds__(kPlaneWaves * 64) void unproject_planes_kernel(
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
       if ((ch & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // four rows in flight, not CH
-      const unsigned v = __float_as_uint(s_out[ch * TSTR + lane]);
+      unsigned v = __float_as_uint(s_out[ch * TSTR + lane]);
+      v = v == 0x80000000u ? 0u : v;  // -0.0 orders as +0.0
       over_x[ch] = v > over_x[ch] ? v : over_x[ch];
       if (v != 0u)
         __hip_atomic_fetch_max(acc + (xs * CH + ch) * kWaveVox + lane, v, __ATOMIC_RELAXED,
@@ -706,7 +709,8 @@ __global__ __launch_bounds__(kPlaneWaves * 64) void unproject_planes_kernel(
 #pragma unroll
         for (int k = 0; k < 16; k++) {
           if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-          const unsigned v = __float_as_uint(row[k]);
+          unsigned v = __float_as_uint(row[k]);
+          v = v == 0x80000000u ? 0u : v;  // -0.0 orders as +0.0
           m = v > m ? v : m;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1068,8 +1072,9 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
     return;  // a skipped item's volume is constant zero: no gradient
 
   unsigned char* wbase = smem + (size_t)wave * a.wave_lds;
-  GroupRec* s_rec = reinterpret_cast<GroupRec*>(wbase);  // [V][64]
-  float* s_den = reinterpret_cast<float*>(wbase + (size_t)a.V * kWaveVox * sizeof(GroupRec));
+  GroupRec* s_rec = reinterpret_cast<GroupRec*>(wbase);  // [slot1 - slot0][64]
+  float* s_den = reinterpret_cast<float*>(
+      wbase + (size_t)(a.slot1 - a.slot0) * kWaveVox * sizeof(GroupRec));
   float* s_g = s_den + kWaveVox;  // [4L][TSTR] incoming gradient, lane = voxel
 
   const float* gout = a.cubes + (long long)b * a.C * a.N;
@@ -1080,6 +1085,8 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
   const bool have = n < a.N && voxel_world<MODE>(a, b, n, &x, &y, &z);
   int cnt = 0;
   unsigned amask = 0;
+  // every view is projected (the masked mean's denominator counts them all); the
+  // footprints of slots [slot0, slot1) are kept and scattered by this launch
 #pragma unroll 1
   for (int slot = 0; slot < a.V; slot++) {
     const int view = slot_view(a, slot);
@@ -1093,7 +1100,8 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
       need = MODE != MODE_ROOT || p.inside || p.px != p.px || p.py != p.py;
     }
     cnt += p.inside;
-    if (__builtin_amdgcn_ballot_w64(need) != 0) {
+    const bool mine = slot >= a.slot0 && slot < a.slot1;  // wave-uniform
+    if (mine && __builtin_amdgcn_ballot_w64(need) != 0) {
       float gx, gy, fw, fn;
       int x0, y0;
       tempo_pixel_to_grid(&cam, p.px, p.py, &a.geom, UNF, &gx, &gy);
@@ -1104,8 +1112,8 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
                 ((need && (unsigned)(x0 + 1) < (unsigned)a.W) ? 2u : 0u);
       r.w = fw;
       r.n = fn;
-      s_rec[slot * kWaveVox + lane] = r;
-      amask |= 1u << slot;
+      s_rec[(slot - a.slot0) * kWaveVox + lane] = r;
+      amask |= 1u << (slot - a.slot0);
     }
   }
   amask = __builtin_amdgcn_readfirstlane(amask);
@@ -1134,9 +1142,9 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
   unsigned mm = amask;
 #pragma unroll 1
   while (mm) {
-    const int slot = __builtin_ctz(mm);
+    const int slot = __builtin_ctz(mm);  // relative to slot0
     mm &= mm - 1;
-    const int view = slot_view(a, slot);
+    const int view = slot_view(a, a.slot0 + slot);
     char* vbase = reinterpret_cast<char*>(a.ghm + (long long)frame * a.frame_stride) +
                   (long long)view * a.view_bytes + c * 4;
 #pragma unroll 4
@@ -1687,15 +1695,26 @@ int launch_backward_one(const UnprojArgs& a, hipStream_t stream) {
   const int waves = kThreads / 64;
   k.tile_vox = waves * kWaveVox;
   k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
-  k.wave_lds = backward_wave_lds(a.V, L);
-  if (waves * k.wave_lds > 65536) return TEMPO_E_DIM;  // too many views for the record table
   const long long total = (long long)a.NB * k.tiles;
   if (total > 0x7fffffffLL / 8) return TEMPO_E_DIM;
   k.total = (int)total;
   k.chunk = (k.total + 7) / 8;
-  hipLaunchKernelGGL((unproject_backward_kernel<MODE, L, UNF>), dim3(8 * k.chunk),
-                     dim3(kThreads), (size_t)waves * k.wave_lds, stream, k);
-  return (int)hipGetLastError();
+  // the footprint records of a launch's views live in LDS (64 KB per workgroup): more
+  // views than fit (11 at CP = 16, 7 at CP = 32) go through in several launches, each of
+  // which projects every view (for the denominator) and scatters its own subset
+  int per = a.V;
+  while (per > 1 && waves * backward_wave_lds(per, L) > 65536) per--;
+  if (waves * backward_wave_lds(per, L) > 65536) return TEMPO_E_DIM;
+  for (int s0 = 0; s0 < a.V; s0 += per) {
+    k.slot0 = s0;
+    k.slot1 = s0 + per < a.V ? s0 + per : a.V;
+    k.wave_lds = backward_wave_lds(k.slot1 - k.slot0, L);
+    hipLaunchKernelGGL((unproject_backward_kernel<MODE, L, UNF>), dim3(8 * k.chunk),
+                       dim3(kThreads), (size_t)waves * k.wave_lds, stream, k);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return TEMPO_OK;
 }
 
 // window backward through the LDS tile (window_backward_brick_kernel)
@@ -1782,6 +1801,9 @@ int launch_mode(const UnprojArgs& a, int mm_unfused, hipStream_t stream) {
   return TEMPO_E_ARG;
 }
 
+// 16-byte alignment of a device pointer the kernels access with 128-bit loads / stores
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 int check_common(int V, int C, int CP, int H, int W) {
   if (V <= 0 || V > TEMPO_MAX_VIEWS || C <= 0 || C > TEMPO_MAX_CHANNELS || H <= 0 ||
       W <= 0)
@@ -1789,11 +1811,6 @@ int check_common(int V, int C, int CP, int H, int W) {
   if (CP % 4 != 0 || CP < C || CP < 16 || CP > TEMPO_MAX_CHANNELS) return TEMPO_E_PAD;
   if ((long long)H * W * CP * 4 >= 0x80000000LL) return TEMPO_E_SIZE;
   return TEMPO_OK;
-}
-
-// the backward keeps one footprint record per view and voxel of a tile in LDS
-bool backward_fits(int V, int CP) {
-  return (kThreads / 64) * (V * kWaveVox * 16 + kWaveVox * 4 + CP * (kWaveVox + 1) * 4) <= 65536;
 }
 
 struct Extra {
@@ -1847,6 +1864,7 @@ int tempo_repack_nhwc(const void* const* views, int V, int B, int C_total, int c
   const int rc = check_common(V, C, CP, H, W);
   if (rc != TEMPO_OK) return rc;
   if (B <= 0 || B > 65535 || c_begin < 0 || c_begin + C > C_total) return TEMPO_E_DIM;
+  if (!aligned16(out)) return TEMPO_E_ARG;  // written with 128-bit stores
   RepackArgs a;
   for (int v = 0; v < V; v++) {
     if (views[v] == nullptr) return TEMPO_E_NULL;
@@ -1991,6 +2009,7 @@ int tempo_unrepack_nchw(const float* in, void* const* views, int V, int B, int C
   const int rc = check_common(V, C, CP, H, W);
   if (rc != TEMPO_OK) return rc;
   if (B <= 0 || B > 65535 || c_begin < 0 || c_begin + C > C_total) return TEMPO_E_DIM;
+  if (!aligned16(in)) return TEMPO_E_ARG;
   UnrepackArgs a;
   for (int v = 0; v < TEMPO_MAX_VIEWS; v++) a.views[v] = nullptr;
   for (int v = 0; v < V; v++) {
@@ -2033,6 +2052,7 @@ int root_impl(const float* hm, const float* cam, const float* ax_x, const float*
   if (!hm || !cam || !ax_x || !ax_y || !ax_z || !cubes) return TEMPO_E_NULL;
   if ((groups == nullptr) != (num_groups == 0) || num_groups < 0 || num_groups > B)
     return TEMPO_E_ARG;
+  if (!aligned16(hm)) return TEMPO_E_ARG;  // texels are fetched with 128-bit buffer loads
   const int rc = check_common(V, C, CP, H, W);
   if (rc != TEMPO_OK) return rc;
   if (B <= 0 || X <= 0 || Y <= 0 || Z <= 0) return TEMPO_E_DIM;
@@ -2043,7 +2063,6 @@ int root_impl(const float* hm, const float* cam, const float* ax_x, const float*
                 mask_bytes == 4))
     return TEMPO_E_ARG;
   if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
-  if (ex.ghm != nullptr && !backward_fits(V, CP)) return TEMPO_E_DIM;
   UnprojArgs a = {};
   a.hm = hm; a.cam = cam;
   a.ax[0] = ax_x; a.ax[1] = ax_y; a.ax[2] = ax_z;
@@ -2098,6 +2117,7 @@ int tempo_root_step(const void* const* views, int C_total, int c_begin, const fl
       X <= 0 || Y <= 0 || Z <= 0)
     return TEMPO_E_DIM;
   if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
+  if (!aligned16(workspace)) return TEMPO_E_ARG;
   for (int v = 0; v < V; v++)
     if (views[v] == nullptr) return TEMPO_E_NULL;
   const long long HW = (long long)H * W;
@@ -2180,6 +2200,7 @@ int window_impl(const float* hm, const float* cam, const int32_t* win_frame, con
   if (!hm || !cam || !fx || !fy || !fz || !tl || !start || !end) return TEMPO_E_NULL;
   if ((groups == nullptr) != (num_groups == 0) || num_groups < 0 || num_groups > NW)
     return TEMPO_E_ARG;
+  if (!aligned16(hm)) return TEMPO_E_ARG;  // texels are fetched with 128-bit buffer loads
   const int rc = check_common(V, C, CP, H, W);
   if (rc != TEMPO_OK) return rc;
   if (NW <= 0 || F <= 0 || FX <= 0 || FY <= 0 || FZ <= 0 || VX <= 0 || VY <= 0 || VZ <= 0)
@@ -2188,7 +2209,6 @@ int window_impl(const float* hm, const float* cam, const int32_t* win_frame, con
   const long long N = (long long)VX * VY * VZ;
   if (N * 4 >= 0x80000000LL) return TEMPO_E_SIZE;
   if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
-  if (ex.ghm != nullptr && !backward_fits(V, CP)) return TEMPO_E_DIM;
   UnprojArgs a = {};
   a.hm = hm; a.cam = cam;
   a.ax[0] = fx; a.ax[1] = fy; a.ax[2] = fz;

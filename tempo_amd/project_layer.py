@@ -238,6 +238,7 @@ class ProjectLayer(nn.Module):
                         want_mask=self.keep_mask)
             cubes = _Unproject.apply(meta, *[fm.float() for fm in feature_maps])
             self.last_mask = meta.get('mask')
+            self.last_zmax = None  # (the training forward does not emit the z-max planes)
             return cubes, meta.get('grids')
         cubes = torch.empty(B, C, *cube_size, dtype=torch.float32, device=device)
         grids = mask = None

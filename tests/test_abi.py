@@ -94,7 +94,7 @@ def test_new_entry_points_reject_bad_arguments():
         kw.get('mm', 0), None)
     assert bwd(g=None) == -1 and bwd(cmask=None) == -1 and bwd(ghm=None) == -1
     assert bwd(mm=1) == -5
-    assert bwd(V=13) == -2                  # footprint records of 13 views exceed the LDS budget
+    assert bwd(V=33) == -2                  # beyond TEMPO_MAX_VIEWS (13+ views: several launches)
     wbwd = lambda **kw: lib.tempo_unproject_window_backward(
         one, one, None, one, one, one, one, one, one, None, one, kw.get('ghm', one),
         kw.get('NW', 4), 4, 5, 15, 16, 128, 240, 253, 253, 64, 64, 64, 64, 240.0, 128.0, 960.0,
@@ -106,3 +106,21 @@ def test_new_entry_points_reject_bad_arguments():
     ptrs = (ctypes.c_void_p * 2)(16, 16)
     assert lib.tempo_unrepack_nchw(None, ptrs, 2, 1, 15, 0, 15, 8, 8, 16, None) == -1
     assert lib.tempo_unrepack_nchw(one, ptrs, 2, 1, 15, 4, 15, 8, 8, 16, None) == -2
+
+
+def test_misaligned_channel_last_buffers_are_rejected():
+    """hm / workspace / the repack's out are accessed with 128-bit loads and stores."""
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    one, odd = P(16), P(20)
+    ptrs = (ctypes.c_void_p * 2)(16, 16)
+    assert lib.tempo_repack_nhwc(ptrs, 2, 1, 15, 0, 15, 8, 8, 16, odd, None) == -5
+    assert lib.tempo_unproject_root(odd, one, one, one, one, 0, None, one, None, None, 0, 1, 5,
+                                    15, 16, 128, 240, 8, 8, 8, 240.0, 128.0, 960.0, 512.0, 0,
+                                    None) == -5
+    assert lib.tempo_unproject_window(odd, one, None, one, one, one, one, one, one, None, one,
+                                      4, 4, 5, 15, 16, 128, 240, 253, 253, 64, 64, 64, 64,
+                                      240.0, 128.0, 960.0, 512.0, 0, None) == -5
+    assert lib.tempo_root_step(ptrs, 15, 0, one, one, one, one, 0, None, one, None, None, 0, 1,
+                               2, 15, 16, 8, 8, 4, 4, 4, 8.0, 8.0, 8.0, 8.0, 0, odd, 1,
+                               None) == -5

@@ -283,3 +283,49 @@ def test_more_than_32_channels_goes_through_slices(gpu_device):
     cubes, _ = layer(fms, gc, *args[2:])
     (cubes * weight.to(gpu_device)).sum().backward()
     _grads_close([f.grad for f in fms], [f.grad for f in ref_fms], 'window 40 channels')
+
+
+@pytest.mark.parametrize('views,joints', [(12, 15), (13, 15), (8, 30), (16, 17)])
+def test_root_backward_with_more_views_than_one_launch_holds(views, joints, gpu_device):
+    """The root backward keeps per-view footprints in LDS (11 views at CP=16, 7 at CP=32):
+    more views go through in several launches.  Against autograd through the oracle."""
+    import tempo_amd
+    spec = dict(cfg='panoptic', B=1, cube=[10, 9, 7], hm='blobs', seed=61, num_views=views,
+                num_joints=joints)
+    case = cases.build_root(None, full=spec)
+    args = list(case['args'])
+    ref_fms = _leafs(args[0])
+    ref_cubes, _ = O.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')(
+        ref_fms, *args[1:])
+    g = torch.Generator().manual_seed(9)
+    weight = torch.randn(ref_cubes.shape, generator=g)
+    (ref_cubes * weight).sum().backward()
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    fms = _leafs(args[0], gpu_device)
+    cubes, _ = layer(fms, *args[1:])
+    # V >= 16: torch's view-sum order is reproduced to rounding only (unproject_math.h)
+    assert float((cubes.detach().cpu() - ref_cubes.detach()).abs().max()) <= (
+        1e-5 if views < 16 else 1e-4)
+    (cubes * weight.to(gpu_device)).sum().backward()
+    _grads_close([f.grad for f in fms], [f.grad for f in ref_fms], f'V={views} J={joints}')
+
+
+def test_window_backward_many_views(gpu_device):
+    """The default window backward keeps no per-view records: any view count."""
+    import tempo_amd
+    spec = dict(cfg='panoptic', B=2, sub_cube=[12, 12, 12], hm='blobs', seed=62,
+                space=[2000, 2000, 2000], sub=[1000, 1000, 1000], num_views=13,
+                invalid_every=0)
+    case = cases.build_window(None, full=spec)
+    args = list(case['args'])
+    ref_fms = _leafs(args[0])
+    ref_cubes, _ = O.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')(
+        ref_fms, *args[1:])
+    g = torch.Generator().manual_seed(10)
+    weight = torch.randn(ref_cubes.shape, generator=g)
+    (ref_cubes * weight).sum().backward()
+    layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    fms = _leafs(args[0], gpu_device)
+    cubes, _ = layer(fms, args[1].to(gpu_device), *args[2:])
+    (cubes * weight.to(gpu_device)).sum().backward()
+    _grads_close([f.grad for f in fms], [f.grad for f in ref_fms], 'window V=13')
