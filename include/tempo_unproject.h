@@ -13,7 +13,8 @@
  *  - return value: 0 = ok, < 0 = TEMPO_E_* (bad argument, nothing launched),
  *    > 0 = a hipError_t from the launch.  Nothing throws or exits;
  *  - re-entrant: no mutable globals; concurrent calls on different streams
- *    are safe as long as their output buffers do not overlap;
+ *    are safe as long as their output buffers do not overlap (one exception,
+ *    stated there: tempo_root_step_static);
  *  - heatmap buffers in channel-last layout (hm, grad_hm, the repack's out, the
  *    root step's workspace) must be 16-byte aligned: they are accessed with
  *    128-bit loads and stores (TEMPO_E_ARG otherwise);
@@ -51,6 +52,8 @@ extern "C" {
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
+/* bytes of the per-GPU static staging array of tempo_root_step_static */
+#define TEMPO_STATIC_SCRATCH_BYTES (64u << 20)
 #define TEMPO_MM_FMA 0
 #define TEMPO_MM_UNFUSED 7
 
@@ -137,6 +140,30 @@ int tempo_root_step(const void* const* views, int C_total, int c_begin,
                     int V, int C, int CP, int H, int W, int X, int Y, int Z,
                     float hm_w, float hm_h, float img_w, float img_h,
                     int mm_unfused, float* workspace, int chunk, void* stream);
+
+/* tempo_root_step that allocates nothing and takes no workspace.  NO COUNTERPART IN
+ * THE REFERENCE: it exists for callers that cannot call hipMalloc or bring a
+ * workspace -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid allocation.  The channel-last staging buffer is a file-scope __device__
+ * array of TEMPO_STATIC_SCRATCH_BYTES (64 MiB) that every GPU the library runs on
+ * holds until the process ends; its device address is looked up once per device
+ * (hipGetSymbolAddress) at the first call made with that device current.  The
+ * call itself performs no hipMalloc / hipFree / allocating library call.
+ *   chunk : frames per repack+unproject chunk, cut to what fits the array
+ *           (6 frames at the Panoptic cam5 sizes, 1 at H36M 4 x 384 x 384 x 20)
+ * Limit: one frame's maps, V*H*W*CP*4 bytes, must fit the array (TEMPO_E_SIZE
+ * otherwise).  Results are bit-identical to tempo_root_step.  Every call on a GPU
+ * shares that GPU's array (it keeps the last call's maps; nothing needs to start at
+ * zero, every chunk is fully rewritten before it is read): calls that overlap in
+ * time on ONE GPU -- different streams or threads -- race on it and must be
+ * serialised by the caller.  All other arguments as tempo_root_step. */
+int tempo_root_step_static(const void* const* views, int C_total, int c_begin,
+                           const float* cam, const float* ax_x, const float* ax_y,
+                           const float* ax_z, int ax_batched, const uint8_t* live,
+                           float* cubes, float* grids, void* mask, int mask_bytes,
+                           int B, int V, int C, int CP, int H, int W, int X, int Y,
+                           int Z, float hm_w, float hm_h, float img_w, float img_h,
+                           int mm_unfused, int chunk, void* stream);
 
 /* tempo_unproject_root for a batch in which runs of consecutive items share one
  * calibration and one grid -- the frames of one recording; the reference

@@ -48,6 +48,9 @@ SIGNATURES = {
     'tempo_root_step': (_c_int, [ctypes.POINTER(_c_void_p), _c_int, _c_int] + [_c_void_p] * 4 +
                         [_c_int] + [_c_void_p] * 4 + [_c_int] * 10 + [_c_float] * 4 +
                         [_c_int, _c_void_p, _c_int, _c_void_p]),
+    'tempo_root_step_static': (_c_int, [ctypes.POINTER(_c_void_p), _c_int, _c_int] +
+                               [_c_void_p] * 4 + [_c_int] + [_c_void_p] * 4 + [_c_int] * 10 +
+                               [_c_float] * 4 + [_c_int, _c_int, _c_void_p]),
     'tempo_unproject_root_zmax': (_c_int, [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 4 +
                                   [_c_int] * 10 + [_c_float] * 4 +
                                   [_c_int, _c_void_p, _c_void_p]),

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "../../include/tempo_unproject.h"
@@ -1846,7 +1847,9 @@ const char* tempo_error_string(int code) {
     case TEMPO_E_NULL: return "tempo: a required pointer is NULL";
     case TEMPO_E_DIM: return "tempo: a dimension is <= 0 or exceeds the library limit";
     case TEMPO_E_PAD: return "tempo: padded channel count must be a multiple of 4 in [max(C,16), 32]";
-    case TEMPO_E_SIZE: return "tempo: one view's map or one volume exceeds 2^31 bytes";
+    case TEMPO_E_SIZE:
+      return "tempo: one view's map or one volume exceeds 2^31 bytes, or one frame's maps "
+             "exceed the static scratch of tempo_root_step_static";
     case TEMPO_E_ARG: return "tempo: inconsistent argument";
     default: return code > 0 ? hipGetErrorString((hipError_t)code) : "tempo: unknown error";
   }
@@ -2141,6 +2144,69 @@ int tempo_root_step(const void* const* views, int C_total, int c_begin, const fl
                     mm_unfused, nullptr, 0, Extra(), stream);
   }
   return err;
+}
+
+}  // extern "C"
+
+// ------------------------------------------- entry point that allocates nothing
+// For callers that cannot call hipMalloc (HIP graph capture, serving loops, harnesses that
+// forbid it): tempo_root_step with its channel-last staging buffer in a file-scope device
+// array instead of a caller-allocated workspace.  Every GPU the library runs on holds its own
+// copy of the array at its own address until the process ends; the host-side name `scratch`
+// is only a handle for hipGetSymbolAddress, never a device address.
+namespace {
+
+static __device__ __align__(256) unsigned char scratch[TEMPO_STATIC_SCRATCH_BYTES];
+
+constexpr int kMaxDevices = 64;
+float* g_scratch_ptr[kMaxDevices];  // per device, filled at the first call on that device
+std::mutex g_scratch_mutex;
+
+// device address of `scratch` on the current device (looked up once per device)
+int static_scratch(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= kMaxDevices) return TEMPO_E_DIM;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return (int)e;
+    if (p == nullptr) return TEMPO_E_NULL;
+    g_scratch_ptr[dev] = static_cast<float*>(p);
+  }
+  *out = g_scratch_ptr[dev];
+  return TEMPO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tempo_root_step_static(const void* const* views, int C_total, int c_begin,
+                           const float* cam, const float* ax_x, const float* ax_y,
+                           const float* ax_z, int ax_batched, const uint8_t* live,
+                           float* cubes, float* grids, void* mask, int mask_bytes, int B,
+                           int V, int C, int CP, int H, int W, int X, int Y, int Z,
+                           float hm_w, float hm_h, float img_w, float img_h, int mm_unfused,
+                           int chunk, void* stream) {
+  const int rc = check_common(V, C, CP, H, W);
+  if (rc != TEMPO_OK) return rc;
+  if (chunk <= 0) return TEMPO_E_DIM;
+  // one frame's channel-last maps must fit the static array; the chunk is cut to what fits
+  const long long frame_bytes = (long long)V * H * W * CP * 4;
+  if (frame_bytes > (long long)TEMPO_STATIC_SCRATCH_BYTES) return TEMPO_E_SIZE;
+  const long long fit = (long long)TEMPO_STATIC_SCRATCH_BYTES / frame_bytes;
+  if (chunk > fit) chunk = (int)fit;
+  float* ws = nullptr;
+  const int e = static_scratch(&ws);
+  if (e != TEMPO_OK) return e;
+  // (nothing to clear: the repack overwrites every byte of a chunk's region, padding
+  // channels included, before the unprojection of that chunk reads it)
+  return tempo_root_step(views, C_total, c_begin, cam, ax_x, ax_y, ax_z, ax_batched, live,
+                         cubes, grids, mask, mask_bytes, B, V, C, CP, H, W, X, Y, Z, hm_w, hm_h,
+                         img_w, img_h, mm_unfused, ws, chunk, stream);
 }
 
 int tempo_unproject_window(const float* hm, const float* cam, const int32_t* win_frame,
