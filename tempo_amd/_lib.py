@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TEMPO_LIB') or os.path.join(_HERE, 'lib', 'libtempo_unproject.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_void_p, _c_int, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
@@ -51,9 +51,28 @@ SIGNATURES = {
     'tempo_root_step_static': (_c_int, [ctypes.POINTER(_c_void_p), _c_int, _c_int] +
                                [_c_void_p] * 4 + [_c_int] + [_c_void_p] * 4 + [_c_int] * 10 +
                                [_c_float] * 4 + [_c_int, _c_int, _c_void_p]),
+    'tempo_unproject_root_views': (_c_int, [ctypes.POINTER(_c_void_p), ctypes.c_longlong, _c_int] +
+                                   [_c_void_p] * 4 + [_c_int] + [_c_void_p] * 4 + [_c_int] * 10 +
+                                   [_c_float] * 4 + [_c_int, _c_void_p]),
+    'tempo_unproject_window_views': (_c_int, [ctypes.POINTER(_c_void_p), ctypes.c_longlong,
+                                              _c_int] + [_c_void_p] * 10 + [_c_int] * 13 +
+                                     [_c_float] * 4 + [_c_int, _c_void_p]),
+    'tempo_footprint_words': (ctypes.c_longlong, [_c_int, ctypes.c_longlong]),
+    'tempo_project_footprints': (_c_int, [_c_void_p] * 4 + [_c_int] * 8 + [_c_float] * 4 +
+                                 [_c_int, _c_int, _c_void_p, _c_void_p]),
+    'tempo_gather_root': (_c_int, [ctypes.POINTER(_c_void_p), ctypes.c_longlong, _c_int,
+                                   _c_void_p, _c_void_p, _c_int] + [_c_void_p] * 7 +
+                          [_c_int, _c_void_p] + [_c_int] * 9 + [_c_void_p]),
+    'tempo_gather_window': (_c_int, [ctypes.POINTER(_c_void_p), ctypes.c_longlong, _c_int,
+                                     _c_void_p, _c_void_p, _c_int] + [_c_void_p] * 6 +
+                            [_c_int] * 13 + [_c_void_p]),
+    'tempo_root_step_shared': (_c_int, [ctypes.POINTER(_c_void_p), _c_int, _c_int, _c_void_p,
+                                        _c_int] + [_c_void_p] * 8 + [_c_int] * 10 +
+                               [_c_float] * 4 + [_c_int, _c_void_p, _c_void_p, _c_int, _c_void_p]),
     'tempo_unproject_root_zmax': (_c_int, [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 4 +
                                   [_c_int] * 10 + [_c_float] * 4 +
                                   [_c_int, _c_void_p, _c_void_p]),
+    'tempo_gather_zcolumns': (_c_int, [_c_void_p] * 3 + [_c_int] * 6 + [_c_void_p]),
     'tempo_project_points': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int] +
                              [_c_float] * 4 + [_c_int] + [_c_void_p] * 4),
 }

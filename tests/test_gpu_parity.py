@@ -280,6 +280,63 @@ def test_root_forward_sequence_equals_loop(gpu_device):
                                      [d['args'][6] for d in ds])
     canon = lambda t: torch.nan_to_num(t, nan=-1.0)
     assert seq.shape == loop.shape and torch.equal(canon(seq), canon(loop))
+    # and against the oracle's own loop over time_idx (tempo_detector.py:175-191)
+    ref_layer = O.ProjectLayer(cs[0]['image_size'], cs[0]['heatmap_size'], 'mean')
+    ref = torch.cat([ref_layer(*c['args'])[0] for c in cs], dim=0)
+    assert torch.equal(seq.cpu().isnan(), ref.isnan())
+    assert float((canon(seq.cpu()) - canon(ref)).abs().max()) <= TOL
+
+
+def test_window_step_ten_proposals_per_frame_vs_oracle(gpu_device):
+    """BASELINE config 3's batched shape: P proposals per frame (window j looks at frame
+    j // P), frames sent through in chunks (ops.window_step) -- against the oracle called
+    the reference's way, one proposal per batch item (tempo_pose.py:266 loops over n)."""
+    import tempo_amd
+    from tempo_amd import ops, synthetic as S
+    from tempo_amd.camera import pack_cameras
+    cfg = S.PANOPTIC
+    F_, P = 3, 10
+    space, sub, sub_cube = [2400, 2400, 1800], [1200, 1200, 900], [12, 12, 12]
+    cams = [S.ring_cameras(5, seed=80 + b, target=cfg['space_center']) for b in range(F_)]
+    metas = [S.frame_meta(cams[b], 1, cfg['raw_size'], cfg['image_size']) for b in range(F_)]
+    centers = [m[0][0] for m in metas]
+    scales = [m[1][0] for m in metas]
+    cameras = [m[2][0] for m in metas]
+    w, h = cfg['heatmap_size']
+    J = cfg['num_joints']
+    fms = S.make_heatmaps(F_, 5, J, h, w, kind='noise', seed=81)
+    props = S.make_proposals(F_ * P, cfg['space_center'], space, seed=82, invalid_every=7,
+                             margin=0.0).view(F_, P, 7)
+    layer = tempo_amd.ProjectLayerWithMask(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    layer.set_space_size(cfg['space_center'], space, sub, sub_cube, gpu_device)
+    flat = props.view(F_ * P, 7).to(gpu_device)  # ordered (frame, proposal)
+    tl, _, st, en = layer.window_geometry(flat)
+    layer._ensure_grids(gpu_device)
+    geo = [t.to(torch.int32).contiguous() for t in (tl, st, en)]
+    live = (flat[:, 3] >= 0).to(torch.uint8).contiguous()
+    cam = pack_cameras(centers, scales, cameras, cfg['image_size']).to(gpu_device)
+    dfms = [f.to(gpu_device) for f in fms]
+    ref_layer = O.ProjectLayerWithMask(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    refs = [ref_layer(fms, props[:, n], cfg['space_center'], space, sub, sub_cube, centers,
+                      scales, cameras)[0] for n in range(P)]
+    ref = torch.stack(refs, dim=1)  # [F,P,C,12,12,12]
+    for chunk in (1, 2, 3):
+        got, _ = ops.window_step(dfms, cam, layer._fine_axes, *geo, sub_cube,
+                                 cfg['heatmap_size'], cfg['image_size'], windows_per_frame=P,
+                                 live=live, chunk=chunk)
+        torch.cuda.synchronize()
+        got = got.view(F_, P, *got.shape[1:]).cpu()
+        err = _report(f'window_step P={P} chunk={chunk}', got, ref)
+        assert err <= TOL
+    assert float(ref.abs().max()) > 0.0
+    # the fused axis-max on the same batched shape
+    got, planes = ops.window_step(dfms, cam, layer._fine_axes, *geo, sub_cube,
+                                  cfg['heatmap_size'], cfg['image_size'], windows_per_frame=P,
+                                  live=live, planes=True, want_cubes=False)
+    assert got is None
+    for pl, dim in zip(planes, (5, 4, 3)):
+        want = ref.max(dim=dim)[0].view(F_ * P, *pl.shape[1:])
+        assert float((pl.cpu() - want).abs().max()) <= TOL
 
 
 def test_window_forward_sequence_planes_equals_loops(gpu_device):
@@ -314,6 +371,18 @@ def test_window_forward_sequence_planes_equals_loops(gpu_device):
                 assert torch.equal(pxy[:, n, t], ref.max(dim=4)[0])
                 assert torch.equal(pxz[:, n, t], ref.max(dim=3)[0])
                 assert torch.equal(pyz[:, n, t], ref.max(dim=2)[0])
+    # and against the oracle's loops over candidates and time_idx (tempo_pose.py:145-176,
+    # :266): cubes, offset and the three axis-max planes
+    ref_layer = O.ProjectLayerWithMask(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    cpu_fms = [[f.cpu() for f in fm] for fm in fms_t]
+    for n in range(P):
+        for t in range(T):
+            ref, ref_off = ref_layer(cpu_fms[t], cand[:, n].cpu(), cfg['space_center'], space,
+                                     sub, sub_cube, centers, scales, cameras)
+            assert float((cubes[:, n, t].cpu() - ref).abs().max()) <= TOL
+            assert torch.equal(off[:, n].cpu(), ref_off)
+            for got, dim in ((pxy, 4), (pxz, 3), (pyz, 2)):
+                assert float((got[:, n, t].cpu() - ref.max(dim=dim)[0]).abs().max()) <= TOL
 
 
 def test_prepacked_camera_table_is_accepted(gpu_device):
