@@ -74,14 +74,12 @@ def parse(argv=None):
     ap.add_argument('--channels', type=int, default=None,
                     help='heatmap channels instead of the config\'s joint count (TEMPO\'s own '
                          'configs unproject 32 learned features)')
-    ap.add_argument('--projection', default='auto', choices=['auto', 'shared', 'per-frame'],
-                    help='shared: one projection per calibration per step (footprint table, '
-                         'built inside every timed step) + gather-only kernel; per-frame: the '
-                         'fused kernel that projects every frame; auto: shared when the batch '
-                         'has fewer calibrations than frames')
-    ap.add_argument('--input-layout', default='nchw', choices=['nchw', 'nhwc'],
+    ap.add_argument('--input-layout', default='nchw', choices=['nchw', 'nhwc', 'nhwc-tight'],
                     help='nchw: V [B,C,H,W] tensors as the reference has them, repacked inside '
-                         'the step; nhwc: torch.channels_last tensors read in place (no repack)')
+                         'the step; nhwc: torch.channels_last tensors whose channel count is '
+                         'padded to a multiple of 4 (what a channel-last 2-D head such as '
+                         'tempo_conv1x1_nhwc writes), read in place, no repack; nhwc-tight: '
+                         'channels_last with exactly C channels (60-byte texels at 15 joints)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--blocks', type=int, default=5,
                     help='timed blocks of --steps steps each; the median block is reported')
@@ -135,6 +133,8 @@ def gpu_blocker(dev, ms=12.0):
 
 class RootWorkload:
     name = 'panoptic_cam5_root_80x80x20_b32'
+    limiter = ('texture path: 16 texel fetches per wave and view at the L1-miss rate '
+               '(DESIGN.md section 4)')
 
     def __init__(self, args, dev, seed):
         from tempo_amd import ops, project_layer as PL
@@ -149,12 +149,6 @@ class RootWorkload:
         if args.share:
             g = ops.share_groups(ops.camera_keys(cam_host), args.group_max)
             self.groups = None if g is None else g.to(dev)
-        cam_cal, cal_of = ops.calibrations(cam_host)
-        self.NC = int(cam_cal.shape[0])
-        self.shared = (args.projection == 'shared' or
-                       (args.projection == 'auto' and self.NC < self.B)) and self.groups is None
-        self.cam_cal = cam_cal.to(dev)
-        self.cal_of = cal_of.to(dev) if self.NC > 1 else None
         self.axes = [(PL._base_axis(cfg['space_size'][i], cfg['cube_size'][i]) +
                       cfg['space_center'][i]).to(dev) for i in range(3)]
         X, Y, Z = cfg['cube_size']
@@ -162,30 +156,27 @@ class RootWorkload:
         w, h = cfg['heatmap_size']
         cp = ops.padded_channels(self.J)
         self.input_layout = args.input_layout
-        self.nhwc = args.input_layout == 'nhwc'
-        if self.nhwc:  # what a channels_last 2-D head hands over: same values, NHWC memory
-            self.fms = [f.contiguous(memory_format=torch.channels_last) for f in self.fms]
+        self.nhwc = args.input_layout != 'nchw'
+        if self.nhwc:
             if self.groups is not None:
                 raise SystemExit('--share works on repacked maps only')
+            # what a channel-last 2-D head hands over: the same values in NHWC memory; the
+            # padded form carries cp - J zero channels per texel
+            pad = cp - self.J if args.input_layout == 'nhwc' else 0
+            self.fms = [torch.nn.functional.pad(f, (0, 0, 0, 0, 0, pad)).contiguous(
+                memory_format=torch.channels_last) for f in self.fms]
         # frames go through in chunks that reuse one channel-last buffer (ops.root_step);
         # the grouped launch works on the whole batch
         auto = ops.chunk_frames(self.V, h, w, cp)
         self.chunk = self.B if self.groups is not None else min(args.chunk or auto, self.B)
         self.hm = torch.empty(self.chunk, self.V, h, w, cp, device=dev)
         self.out = torch.empty(self.B, self.J, X, Y, Z, device=dev)
-        self.table = (torch.empty(self.NC * ops.footprint_words(self.V, self.N),
-                                  dtype=torch.int32, device=dev) if self.shared else None)
-        self.texel_bytes = 4 * self.J if self.nhwc else 4 * cp
         self.samples = self.B * self.N * self.V
         # volume written once + every heatmap element read once + cameras
         self.kernel_bytes = (4 * self.B * self.J * self.N + 4 * self.B * self.V * self.J * h * w
                              + 128 * self.B * self.V)
         self.kernel_name = ('unproject_group_kernel<ROOT>' if self.groups is not None
-                            else 'gather_kernel<ROOT>' if self.shared
                             else 'unproject_kernel<ROOT>')
-        self.limiter = ('texel gather: L1-miss request rate of the texture path (DESIGN.md 4)'
-                        if self.shared else
-                        'VALU issue of the per-frame projection chain (DESIGN.md 4)')
 
     def _chunks(self):
         return [(c0, min(self.chunk, self.B - c0)) for c0 in range(0, self.B, self.chunk)]
@@ -196,27 +187,13 @@ class RootWorkload:
         n = self.chunk if n is None else n
         self.ops.repack_nhwc([f[c0:c0 + n] for f in self.fms], out=self.hm[:n])
 
-    def build_table(self):
-        ops, cfg = self.ops, self.cfg
-        w, h = cfg['heatmap_size']
-        ops.project_footprints(self.cam_cal, self.axes, h, w, self.texel_bytes,
-                               cfg['heatmap_size'], cfg['image_size'], out=self.table)
-
-    def _layout(self, c0, n):
-        if self.nhwc:
-            return self.ops.channels_last_layout([f[c0:c0 + n] for f in self.fms])
-        return self.ops.packed_layout(self.hm[:n])
-
     def kernel(self, c0=0, n=None):
         n = self.chunk if n is None else n
         cfg = self.cfg
-        if self.shared:
-            self.ops.gather_root(self._layout(c0, n), self.table, self.NC, cfg['cube_size'],
-                                 self.J, cal_of=None if self.cal_of is None
-                                 else self.cal_of[c0:c0 + n], out=self.out[c0:c0 + n])
-        elif self.nhwc:
-            self.ops.unproject_root_views(self._layout(c0, n), self.cam[c0:c0 + n], self.axes,
-                                          self.J, cfg['heatmap_size'], cfg['image_size'],
+        if self.nhwc:
+            lay = self.ops.channels_last_layout([f[c0:c0 + n] for f in self.fms])
+            self.ops.unproject_root_views(lay, self.cam[c0:c0 + n], self.axes, self.J,
+                                          cfg['heatmap_size'], cfg['image_size'],
                                           out=self.out[c0:c0 + n])
         else:
             self.ops.unproject_root(self.hm[:n], self.cam[c0:c0 + n], self.axes, self.J,
@@ -229,19 +206,9 @@ class RootWorkload:
             self.repack(0, self.B)
             self.kernel(0, self.B)
             return
-        if self.nhwc:  # maps read in place: (table +) one launch per chunk of frames
-            if self.shared:
-                self.build_table()
+        if self.nhwc:  # maps read in place: one launch per chunk of frames, no repack
             for c0, n in self._chunks():
                 self.kernel(c0, n)
-            return
-        if self.shared:
-            # one library call: footprint table of the batch's calibrations, then per chunk
-            # repack + gather (tempo_root_step_shared)
-            self.ops.root_step_shared(self.fms, self.cam_cal, self.cal_of, self.axes,
-                                      cfg['heatmap_size'], cfg['image_size'], out=self.out,
-                                      chunk=self.chunk, hm_buf=self.hm.view(-1),
-                                      table=self.table)
             return
         # one library call: tempo_root_step runs the chunk loop (repack + unprojection per
         # chunk, one reused channel-last workspace)
@@ -252,16 +219,12 @@ class RootWorkload:
     def parts(self, steps):
         """(kernel ms, repack ms) per step and kernel launches per step: HIP events around
         every launch, on the launch stream, enqueued behind a blocker so that no interval
-        contains host launch latency.  Adds self.table_ms (projection launch) when shared."""
+        contains host launch latency."""
         steps = min(steps, 10)
         E = lambda: torch.cuda.Event(enable_timing=True)
-        ks, rs, ts = [], [], []
+        ks, rs = [], []
         keep = gpu_blocker(self.dev)
         for _ in range(steps):
-            if getattr(self, 'shared', False):
-                t0, t1 = E(), E()
-                t0.record(); self.build_table(); t1.record()
-                ts.append((t0, t1))
             for c0, n in self._chunks():
                 r0, r1, k0, k1 = E(), E(), E(), E()
                 r0.record(); self.repack(c0, n); r1.record()
@@ -271,7 +234,6 @@ class RootWorkload:
         del keep
         k_ms = sum(a.elapsed_time(b) for a, b in ks) / steps
         r_ms = sum(a.elapsed_time(b) for a, b in rs) / steps
-        self.table_ms = sum(a.elapsed_time(b) for a, b in ts) / steps if ts else None
         return k_ms, r_ms, len(self._chunks())
 
 
@@ -343,27 +305,6 @@ class WindowWorkload:
         self.kernel_name = ('unproject_group_kernel<WINDOW>' if self.groups is not None
                             else 'unproject_planes_kernel' if args.planes != 'off'
                             else 'unproject_kernel<WINDOW>')
-        # one projection of the fine lattice per calibration and step, then gather only
-        from tempo_amd.camera import pack_cameras
-        cam_cal, cal_of = ops.calibrations(self.cam.cpu())
-        self.NC = int(cam_cal.shape[0])
-        self.shared = (args.projection == 'shared' and self.groups is None
-                       and args.planes == 'off')
-        if self.shared:
-            self.cam_cal = cam_cal.to(dev)
-            self.cal_of = cal_of.to(dev)
-            self.fine_dims = [int(a.numel()) for a in self.fine]
-            lat = self.fine_dims[0] * self.fine_dims[1] * self.fine_dims[2]
-            self.table = torch.empty(self.NC * ops.footprint_words(self.V, lat),
-                                     dtype=torch.int32, device=dev)
-            self.kernel_name = 'gather_kernel<WINDOW>'
-
-    def build_table(self):
-        ops, cfg = self.ops, self.cfg
-        w, h = cfg['heatmap_size']
-        ops.project_footprints(self.cam_cal, self.fine, h, w, 4 * self.hm.shape[-1],
-                               cfg['heatmap_size'], cfg['image_size'], window_mode=True,
-                               out=self.table)
 
     def _chunks(self):
         return [(f0, min(self.chunk, self.B - f0)) for f0 in range(0, self.B, self.chunk)]
@@ -380,12 +321,6 @@ class WindowWorkload:
         # inside a chunk the frames are numbered from 0
         wf = self.win_frame if whole else (self.win_frame[ws] - f0).contiguous()
         cam = self.cam if whole else self.cam[f0:f0 + n]
-        if self.shared:
-            self.ops.gather_window(self.ops.packed_layout(self.hm[:n]), self.table, self.NC,
-                                   self.fine_dims, tl, st, en, self.sub, self.J,
-                                   cal_of=self.cal_of if whole else self.cal_of[f0:f0 + n],
-                                   win_frame=wf, out=self.out[ws])
-            return
         if self.planes_mode != 'off':
             self.ops.unproject_window_planes(
                 self.hm[:n], cam, self.fine, tl, st, en, self.sub, self.J,
@@ -399,8 +334,6 @@ class WindowWorkload:
                                   win_frame=wf, out=self.out[ws], groups=self.groups)
 
     def step(self):
-        if self.shared:
-            self.build_table()
         for f0, n in self._chunks():
             self.repack(f0, n)
             self.kernel(f0, n)
@@ -615,7 +548,7 @@ def oracle_check(args, wl, dev):
     from oracle import project_layer_ref as O
     cfg = wl.cfg
     centers, scales, cameras = wl.meta
-    fms = [f[0:1].cpu() for f in wl.fms]
+    fms = [f[0:1, :wl.J].contiguous().cpu() for f in wl.fms]  # (nhwc: drop the pad channels)
     one = ([centers[0]], [scales[0]], [cameras[0]])
     if args.workload in ('root', 'dense'):
         if args.workload == 'dense' and getattr(wl, 'world', 1) > 1:
@@ -780,7 +713,7 @@ def main():
         torch.cuda.synchronize()
         check = oracle_check(args, wl, dev)
         if args.workload == 'root' and not args.no_module and wl.groups is None \
-                and not args.channels:
+                and not args.channels and not wl.nhwc:
             module = module_timing(args, wl, dev)
 
     # fused epilogue: what the reference's caller does instead (tempo_pose.py:172-176) --
@@ -915,11 +848,6 @@ def main():
             'repack_ms': round(r_ms, 4),
             'kernel_gsamp_s': round(wl.samples / (k_ms * 1e-3) / 1e9, 3),
         }
-        line['config']['projection'] = ('shared: one per calibration per step, inside the '
-                                        'timed step' if getattr(wl, 'shared', False)
-                                        else 'per frame')
-        if getattr(wl, 'table_ms', None) is not None:
-            line['footprint_table_ms'] = round(wl.table_ms, 4)
         if comm_ms is not None:
             line['allgather_ms'] = round(comm_ms, 4)
         if check is not None:

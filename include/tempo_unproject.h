@@ -198,76 +198,6 @@ int tempo_unproject_window_views(const void* const* views, long long frame_bytes
                                  float hm_h, float img_w, float img_h, int mm_unfused,
                                  void* stream);
 
-/* ---- one projection per calibration: footprint table + gather.
- * The sample footprint of a (lattice point, view) pair depends on the calibration, the
- * lattice and the map geometry, not on the frame, proposal or timestep; the reference
- * recomputes it for every batch item and view (project_layer.py:80-126) and, in the
- * window variant, for the whole fine lattice per proposal and timestep (:231-268).
- * tempo_project_footprints runs that chain (SimpleCameraTorch.world_to_pixel, bounds
- * test, clamp, affine, normalise, clamp, grid_sample's unnormalise) ONCE per
- * calibration and lattice point; tempo_gather_root / _window then only fetch, mix,
- * average and clamp.  Same operations in the same order: results are bit-identical to
- * tempo_unproject_root / _window.
- *
- * tempo_footprint_words: 32-bit words of table per calibration for V views and a
- * lattice of `lattice_points` points (X*Y*Z of the root grid, FX*FY*FZ of the fine
- * lattice); < 0: TEMPO_E_*.  The layout is private to the library. */
-long long tempo_footprint_words(int V, long long lattice_points);
-
-/*   cam_cal     : [NC, V, 32] packed camera records, one set per calibration
- *   ax_x/y/z    : the lattice's axis vectors [X] [Y] [Z] (root grid axes, or the fine
- *                 lattice's fx/fy/fz)
- *   H, W, texel_bytes : geometry of the maps the gather will read (byte offsets are
- *                 precomputed: the table is tied to it; rows are W * texel_bytes apart)
- *   window_mode : 0 = root rule (views failing the bounds test are not sampled and the
- *                 valid-view bitmap is recorded), 1 = window rule (every view sampled)
- *   table       : out, device uint32 [NC * tempo_footprint_words(V, X*Y*Z)] */
-int tempo_project_footprints(const float* cam_cal, const float* ax_x, const float* ax_y,
-                             const float* ax_z, int NC, int V, int X, int Y, int Z,
-                             int H, int W, int texel_bytes, float hm_w, float hm_h,
-                             float img_w, float img_h, int mm_unfused, int window_mode,
-                             uint32_t* table, void* stream);
-
-/* Root-grid unprojection from a footprint table (window_mode = 0, lattice = the grid).
- *   views, frame_bytes, texel_bytes : as tempo_unproject_root_views, with the H, W,
- *               texel_bytes the table was built for
- *   cal_of    : [B] int32 calibration index of each frame, or NULL (all 0); a frame whose
- *               index is outside [0, NC) is treated like a skipped one (zeros)
- *   ax_x/y/z  : only read to fill `grids`; may be NULL when grids is NULL
- *   zmax      : out fp32 [B, C, X, Y] = max over z (tempo_unproject_root_zmax), or NULL
- * cubes / grids / mask / live as tempo_unproject_root. */
-int tempo_gather_root(const void* const* views, long long frame_bytes, int texel_bytes,
-                      const uint32_t* table, const int32_t* cal_of, int NC,
-                      const float* ax_x, const float* ax_y, const float* ax_z,
-                      const uint8_t* live, float* cubes, float* grids, void* mask,
-                      int mask_bytes, float* zmax, int B, int V, int C, int CP, int H,
-                      int W, int X, int Y, int Z, void* stream);
-
-/* Window unprojection from a footprint table of the fine lattice (window_mode = 1).
- *   cal_of : [F] int32 calibration index of each frame, or NULL (all 0)
- * win_frame / tl / start / end / live / cubes as tempo_unproject_window. */
-int tempo_gather_window(const void* const* views, long long frame_bytes, int texel_bytes,
-                        const uint32_t* table, const int32_t* cal_of, int NC,
-                        const int32_t* win_frame, const int32_t* tl,
-                        const int32_t* start, const int32_t* end, const uint8_t* live,
-                        float* cubes, int NW, int F, int V, int C, int CP, int H, int W,
-                        int FX, int FY, int FZ, int VX, int VY, int VZ, void* stream);
-
-/* tempo_root_step for a batch whose frames come from NC <= B calibrations and share one
- * grid: tempo_project_footprints once, then per chunk tempo_repack_nhwc +
- * tempo_gather_root.  Results are bit-identical to tempo_root_step.
- *   cam_cal : [NC, V, 32]; cal_of : [B] int32 or NULL (NC == 1)
- *   table   : device uint32 workspace [NC * tempo_footprint_words(V, X*Y*Z)]
- *   workspace, chunk, and everything else : as tempo_root_step (axes shared) */
-int tempo_root_step_shared(const void* const* views, int C_total, int c_begin,
-                           const float* cam_cal, int NC, const int32_t* cal_of,
-                           const float* ax_x, const float* ax_y, const float* ax_z,
-                           const uint8_t* live, float* cubes, float* grids, void* mask,
-                           int mask_bytes, int B, int V, int C, int CP, int H, int W,
-                           int X, int Y, int Z, float hm_w, float hm_h, float img_w,
-                           float img_h, int mm_unfused, uint32_t* table,
-                           float* workspace, int chunk, void* stream);
-
 /* tempo_unproject_root for a batch in which runs of consecutive items share one
  * calibration and one grid -- the frames of one recording; the reference
  * re-projects the grid for every item (project_layer.py:80-111).

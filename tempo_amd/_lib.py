@@ -57,18 +57,6 @@ SIGNATURES = {
     'tempo_unproject_window_views': (_c_int, [ctypes.POINTER(_c_void_p), ctypes.c_longlong,
                                               _c_int] + [_c_void_p] * 10 + [_c_int] * 13 +
                                      [_c_float] * 4 + [_c_int, _c_void_p]),
-    'tempo_footprint_words': (ctypes.c_longlong, [_c_int, ctypes.c_longlong]),
-    'tempo_project_footprints': (_c_int, [_c_void_p] * 4 + [_c_int] * 8 + [_c_float] * 4 +
-                                 [_c_int, _c_int, _c_void_p, _c_void_p]),
-    'tempo_gather_root': (_c_int, [ctypes.POINTER(_c_void_p), ctypes.c_longlong, _c_int,
-                                   _c_void_p, _c_void_p, _c_int] + [_c_void_p] * 7 +
-                          [_c_int, _c_void_p] + [_c_int] * 9 + [_c_void_p]),
-    'tempo_gather_window': (_c_int, [ctypes.POINTER(_c_void_p), ctypes.c_longlong, _c_int,
-                                     _c_void_p, _c_void_p, _c_int] + [_c_void_p] * 6 +
-                            [_c_int] * 13 + [_c_void_p]),
-    'tempo_root_step_shared': (_c_int, [ctypes.POINTER(_c_void_p), _c_int, _c_int, _c_void_p,
-                                        _c_int] + [_c_void_p] * 8 + [_c_int] * 10 +
-                               [_c_float] * 4 + [_c_int, _c_void_p, _c_void_p, _c_int, _c_void_p]),
     'tempo_unproject_root_zmax': (_c_int, [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 4 +
                                   [_c_int] * 10 + [_c_float] * 4 +
                                   [_c_int, _c_void_p, _c_void_p]),

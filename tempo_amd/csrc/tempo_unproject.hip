@@ -26,7 +26,6 @@
 // LDS, store 256 contiguous bytes per channel plane and instruction.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include <mutex>
 #include <type_traits>
@@ -115,13 +114,6 @@ struct UnprojArgs {
   long long frame_bytes;
   unsigned map_bytes;  // H * row_bytes: the buffer range of one map
   int texel_bytes, row_bytes;
-  // footprint table (gather kernels): per calibration [V slots][lat_n] records of 3 words,
-  // then [lat_n] valid-view bitmaps
-  const uint32_t* table;
-  const int32_t* cal_of;  // calibration of each frame, or nullptr (all 0)
-  long long cal_words;    // words per calibration = lat_n * (3 V + 1)
-  long long lat_n;        // lattice points: root N, window fdim[0] * fdim[1] * fdim[2]
-  int NC;                 // calibrations in the table
 };
 
 __device__ __forceinline__ int slot_view(const UnprojArgs& a, int slot) {
@@ -1079,591 +1071,6 @@ __global__ __launch_bounds__(kThreads) void unproject_group_kernel(const UnprojA
   }
 }
 
-// ------------------------------------------------------- footprint table + gather
-// The sample footprint of a (lattice point, view) pair depends on the calibration, the
-// lattice and the map geometry -- not on the frame, the proposal or the timestep.  Frames of
-// one recording share their calibration (the reference re-projects the grid for every batch
-// item and view, project_layer.py:80-111; the window variant re-projects the whole fine
-// lattice for every proposal and timestep, :231-268).  footprint_kernel projects each
-// lattice point ONCE per calibration, with the arithmetic of unproject_kernel's phase A, into
-// a 12-byte record; gather_kernel then only fetches and mixes.  Results are bit-identical to
-// unproject_kernel: the same operations in the same order, split over two launches.
-//
-// record (3 words):  [0] byte offset of texel (x0, y0) in its map (a multiple of 4)
-//                        | bit 0: column x0 inside the map and the view needed
-//                        | bit 1: column x0 + 1 inside the map and the view needed
-//                    [1] ix - floor(ix)   [2] iy - floor(iy)      (fp32 bit patterns)
-// after the V * lat_n records of a calibration: lat_n words, bit v = view v passes the
-// bounds test of project_layer.py:113-115 (root; zero in window mode).
-struct FootArgs {
-  const float* cam;  // [NC][V][32]
-  const float* ax[3];
-  uint32_t* table;
-  long long cal_words, lat_n;
-  int dim[3];
-  int V, H, W, texel_bytes, row_bytes;
-  unsigned magic[2];
-  unsigned order[10];
-  TempoGeom geom;
-};
-
-template <int MODE, int UNF>
-__global__ __launch_bounds__(kThreads) void footprint_kernel(const FootArgs a) {
-  const long long n = (long long)blockIdx.x * kThreads + threadIdx.x;
-  const int cal = blockIdx.y;
-  if (n >= a.lat_n) return;
-  unsigned t = __umulhi((unsigned)n, a.magic[0]);
-  unsigned r2 = (unsigned)n - t * (unsigned)a.dim[2];
-  if (r2 >= (unsigned)a.dim[2]) { r2 -= (unsigned)a.dim[2]; t++; }
-  unsigned q0 = __umulhi(t, a.magic[1]);
-  unsigned r1 = t - q0 * (unsigned)a.dim[1];
-  if (r1 >= (unsigned)a.dim[1]) { r1 -= (unsigned)a.dim[1]; q0++; }
-  const float x = a.ax[0][q0], y = a.ax[1][r1], z = a.ax[2][r2];
-  uint32_t* tab = a.table + (long long)cal * a.cal_words;
-  unsigned mbits = 0;
-#pragma unroll 1
-  for (int slot = 0; slot < a.V; slot++) {
-    const int view = (int)((a.order[slot >> 2] >> ((slot & 3) * 8)) & 255u);
-    const TempoCam cam = load_cam(a.cam, cal * a.V + view);
-    const TempoPix p = tempo_world_to_pixel(&cam, x, y, z, UNF);
-    // root: a view that fails the bounds test is multiplied by 0 in the reference, so its
-    // texels are never fetched -- unless a coordinate is NaN (0 * NaN poisons the voxel)
-    const bool need = MODE != MODE_ROOT || p.inside || p.px != p.px || p.py != p.py;
-    mbits |= (unsigned)p.inside << view;
-    float gx, gy, fw, fn;
-    int x0, y0;
-    tempo_pixel_to_grid(&cam, p.px, p.py, &a.geom, UNF, &gx, &gy);
-    tempo_bilinear_frac(gx, gy, a.W, a.H, &x0, &y0, &fw, &fn);
-    const unsigned base = (unsigned)texel_offset(y0, x0, a.row_bytes, a.texel_bytes);
-    const unsigned flags = ((need && (unsigned)x0 < (unsigned)a.W) ? 1u : 0u) |
-                           ((need && (unsigned)(x0 + 1) < (unsigned)a.W) ? 2u : 0u);
-    uint32_t* r = tab + ((long long)slot * a.lat_n + n) * 3;
-    r[0] = base | flags;
-    r[1] = __float_as_uint(fw);
-    r[2] = __float_as_uint(fn);
-  }
-  tab[(long long)a.V * a.lat_n * 3 + n] = MODE == MODE_ROOT ? mbits : 0u;
-}
-
-struct __align__(16) GatherRec {
-  unsigned offA, offB;  // byte offsets of texels (x0, y0) and (x0 + 1, y0), or kInvalid
-  float w, n;           // ix - floor(ix), iy - floor(iy)
-};
-
-// LDS bytes per wave: the records of all views, then (den, 1/den) per voxel; the output
-// tile [4L][65] reuses the records' space
-constexpr int gather_wave_lds(int V, int L) {
-  const int rec = V * kWaveVox * (int)sizeof(GatherRec);
-  const int out = 4 * L * (kWaveVox + 1) * 4;
-  return (rec > out ? rec : out) + kWaveVox * 8;
-}
-
-template <int MODE, int L>
-__global__ __launch_bounds__(kThreads) void gather_kernel(const UnprojArgs a) {
-  constexpr int VPS = 64 / L;
-  constexpr int NSUB = (kWaveVox + VPS - 1) / VPS;
-  constexpr int G = (NSUB + 1) / 2;  // sub-steps per half view
-  constexpr int TSTR = kWaveVox + 1;
-  extern __shared__ __align__(16) unsigned char smem[];
-
-  const int bid = blockIdx.x;
-  const int run = bid >> 3;
-  const int item = (bid & 7) * a.chunk + run;  // XCD-aware order, as unproject_kernel
-  if (run >= a.chunk || item >= a.total) return;
-  const int b = __builtin_amdgcn_readfirstlane(item / a.tiles);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n0 = (item - b * a.tiles) * a.tile_vox + wave * kWaveVox;
-  if (n0 >= a.N) return;
-  const int n = n0 + lane;
-
-  int frame = b;
-  if (MODE == MODE_WINDOW && a.win_frame != nullptr) frame = uniform_load(a.win_frame, b);
-  int cal = 0;
-  const bool frame_ok = (unsigned)frame < (unsigned)a.F;
-  if (frame_ok && a.cal_of != nullptr) cal = uniform_load(a.cal_of, frame);
-  const bool dead = (a.live != nullptr && uniform_load_u8(a.live, b) == 0) || !frame_ok ||
-                    (unsigned)cal >= (unsigned)a.NC;
-  if (dead) {
-    if (n < a.N) {
-      if (a.cubes != nullptr)
-        for (int ch = 0; ch < a.C; ch++) a.cubes[((long long)b * a.C + ch) * a.N + n] = 0.0f;
-      if (a.grids != nullptr) {
-        float* g = a.grids + ((long long)b * a.N + n) * 3;
-        g[0] = g[1] = g[2] = 0.0f;
-      }
-      if (a.mask != nullptr) {
-        uint8_t* m = (uint8_t*)a.mask + ((long long)b * a.N + n) * a.mask_bytes;
-        for (int k = 0; k < a.mask_bytes; k++) m[k] = 0;
-      }
-    }
-    return;
-  }
-
-  unsigned char* wbase = smem + (size_t)wave * a.wave_lds;
-  GatherRec* s_rec = reinterpret_cast<GatherRec*>(wbase);  // [V][64]
-  float* s_out = reinterpret_cast<float*>(wbase);           // [4L][TSTR], after the gather
-  float2* s_den = reinterpret_cast<float2*>(wbase + a.wave_lds - kWaveVox * 8);
-
-  // ---- this lane's lattice point
-  long long li = 0;
-  bool have = n < a.N;
-  {
-    int i0 = 0, i1 = 0, i2 = 0;
-    voxel_index(a, have ? n : 0, &i0, &i1, &i2);
-    if (MODE == MODE_ROOT) {
-      li = n;
-      if (a.grids != nullptr && have) {
-        float* g = a.grids + ((long long)b * a.N + n) * 3;
-        g[0] = a.ax[0][i0];
-        g[1] = a.ax[1][i1];
-        g[2] = a.ax[2][i2];
-      }
-    } else {
-      const int f0 = uniform_load(a.tl, 3 * b + 0) + i0;
-      const int f1 = uniform_load(a.tl, 3 * b + 1) + i1;
-      const int f2 = uniform_load(a.tl, 3 * b + 2) + i2;
-      have = have &&
-          f0 >= uniform_load(a.start, 3 * b + 0) && f0 < uniform_load(a.end, 3 * b + 0) &&
-          f1 >= uniform_load(a.start, 3 * b + 1) && f1 < uniform_load(a.end, 3 * b + 1) &&
-          f2 >= uniform_load(a.start, 3 * b + 2) && f2 < uniform_load(a.end, 3 * b + 2) &&
-          (unsigned)f0 < (unsigned)a.fdim[0] && (unsigned)f1 < (unsigned)a.fdim[1] &&
-          (unsigned)f2 < (unsigned)a.fdim[2];
-      li = ((long long)f0 * a.fdim[1] + f1) * a.fdim[2] + f2;
-    }
-  }
-  const uint32_t* tab = a.table + (long long)cal * a.cal_words;
-  unsigned mbits = 0;
-  if (MODE == MODE_ROOT && have) mbits = tab[(long long)a.V * a.lat_n * 3 + li];
-
-  // ---- records of all views: table -> LDS, four loads in flight
-  unsigned amask = 0;  // slots some lane of the wave needs
-  const unsigned tb = (unsigned)a.texel_bytes;
-#pragma unroll 1
-  for (int s0 = 0; s0 < a.V; s0 += 4) {
-    unsigned r[4][3];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int slot = s0 + k < a.V ? s0 + k : a.V - 1;
-      const uint32_t* q = tab + ((long long)slot * a.lat_n + (have ? li : 0)) * 3;
-      r[k][0] = q[0];
-      r[k][1] = q[1];
-      r[k][2] = q[2];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (s0 + k < a.V) {
-        const unsigned x = have ? r[k][0] : 0u;
-        const unsigned base = x & ~3u;
-        GatherRec g;
-        g.offA = (x & 1u) ? base : kInvalid;
-        g.offB = (x & 2u) ? base + tb : kInvalid;
-        g.w = __uint_as_float(r[k][1]);
-        g.n = __uint_as_float(r[k][2]);
-        s_rec[(s0 + k) * kWaveVox + lane] = g;
-        if (__builtin_amdgcn_ballot_w64((x & 3u) != 0u) != 0) amask |= 1u << (s0 + k);
-      }
-    }
-  }
-  amask = __builtin_amdgcn_readfirstlane(amask);
-  {
-    const float den = (MODE == MODE_ROOT ? (float)__builtin_popcount(mbits) : (float)a.V) + 1e-6f;
-    s_den[lane] = make_float2(den, 1.0f / den);
-    if (MODE == MODE_ROOT && a.mask != nullptr && n < a.N) {
-      char* m = (char*)a.mask + ((long long)b * a.N + n) * a.mask_bytes;
-      if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mbits;
-      else if (a.mask_bytes == 2) *(uint16_t*)m = (uint16_t)mbits;
-      else *(uint32_t*)m = mbits;
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-  // ---- gather layout: L lanes per voxel, VPS voxels per sub-step
-  const bool lane_on = lane < VPS * L;
-  const int vq = lane / L;
-  const int cq = lane - vq * L;
-  const unsigned lo = (unsigned)cq * 16u;
-  const unsigned rowb = (unsigned)a.row_bytes;
-  float2 dr[NSUB];
-  int rdv[NSUB];
-#pragma unroll
-  for (int s = 0; s < NSUB; s++) {
-    const int vsl = s * VPS + vq;
-    rdv[s] = (lane_on && vsl < kWaveVox) ? vsl : 0;
-    dr[s] = s_den[rdv[s]];
-  }
-
-  u32x4 tex[2][G][4];
-  // half h of the view in `slot` -> tex[h].  Always issued (an unconditional instruction
-  // stream keeps the wait counts exact); `real` = false reads a zero-sized buffer
-  auto fetch = [&](auto hc, int slot, bool real) {
-    constexpr int h = decltype(hc)::value;
-    const __amdgpu_buffer_rsrc_t rs = map_rsrc(a, frame, slot_view(a, slot), real);
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-      const int s = h * G + g;
-      if (s < NSUB) {
-        const GatherRec r = s_rec[slot * kWaveVox + rdv[s]];
-        // (the row pitch goes into the per-lane offset: a scalar offset is not part of
-        // the buffer's range check, which is what zero-pads rows -1 and H)
-        const unsigned oa = r.offA + lo, ob = r.offB + lo;
-        tex[h][g][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, oa, 0, 0);
-        tex[h][g][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, ob, 0, 0);
-        tex[h][g][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, oa + rowb, 0, 0);
-        tex[h][g][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, ob + rowb, 0, 0);
-      }
-    }
-  };
-  f32x2 acc01[NSUB], acc23[NSUB];
-#pragma unroll
-  for (int s = 0; s < NSUB; s++) {
-    acc01[s] = tempo_splat(0.f);
-    acc23[s] = tempo_splat(0.f);
-  }
-  auto mix = [&](auto hc, int slot) {
-    constexpr int h = decltype(hc)::value;
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-      const int s = h * G + g;
-      if (s < NSUB) {
-        const GatherRec r = s_rec[slot * kWaveVox + rdv[s]];
-        // the weights of tempo_bilinear_tap, from the stored fractions
-        const float e = 1.0f - r.w, sth = 1.0f - r.n;
-        const f32x2 nw = tempo_splat(sth * e), ne = tempo_splat(sth * r.w);
-        const f32x2 sw = tempo_splat(r.n * e), se = tempo_splat(r.n * r.w);
-        const f32x2 a01 = {__uint_as_float(tex[h][g][0][0]), __uint_as_float(tex[h][g][0][1])};
-        const f32x2 a23 = {__uint_as_float(tex[h][g][0][2]), __uint_as_float(tex[h][g][0][3])};
-        const f32x2 b01 = {__uint_as_float(tex[h][g][1][0]), __uint_as_float(tex[h][g][1][1])};
-        const f32x2 b23 = {__uint_as_float(tex[h][g][1][2]), __uint_as_float(tex[h][g][1][3])};
-        const f32x2 c01 = {__uint_as_float(tex[h][g][2][0]), __uint_as_float(tex[h][g][2][1])};
-        const f32x2 c23 = {__uint_as_float(tex[h][g][2][2]), __uint_as_float(tex[h][g][2][3])};
-        const f32x2 d01 = {__uint_as_float(tex[h][g][3][0]), __uint_as_float(tex[h][g][3][1])};
-        const f32x2 d23 = {__uint_as_float(tex[h][g][3][2]), __uint_as_float(tex[h][g][3][3])};
-        f32x2 v01 = a01 * nw, v23 = a23 * nw;
-        v01 = __builtin_elementwise_fma(b01, ne, v01);
-        v23 = __builtin_elementwise_fma(b23, ne, v23);
-        v01 = __builtin_elementwise_fma(c01, sw, v01);
-        v23 = __builtin_elementwise_fma(c23, sw, v23);
-        v01 = __builtin_elementwise_fma(d01, se, v01);
-        v23 = __builtin_elementwise_fma(d23, se, v23);
-        acc01[s] = acc01[s] + v01;
-        acc23[s] = acc23[s] + v23;
-      }
-    }
-  };
-  using H0 = std::integral_constant<int, 0>;
-  using H1 = std::integral_constant<int, 1>;
-
-  // slots in torch's summation order; two half views of fetches in flight: the next half
-  // is issued before each mix
-  {
-    unsigned mm = amask;
-    fetch(H0{}, mm ? __builtin_ctz(mm) : 0, mm != 0);
-#pragma unroll 1
-    while (mm) {
-      const int slot = __builtin_ctz(mm);
-      mm &= mm - 1;
-      __builtin_amdgcn_sched_barrier(0);
-      fetch(H1{}, slot, true);
-      __builtin_amdgcn_sched_barrier(0);
-      mix(H0{}, slot);
-      __builtin_amdgcn_sched_barrier(0);
-      fetch(H0{}, mm ? __builtin_ctz(mm) : 0, mm != 0);
-      __builtin_amdgcn_sched_barrier(0);
-      mix(H1{}, slot);
-    }
-  }
-
-  // ---- normalise, clamp, transpose, store (unproject_wave's phase C)
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  bool odd = false;
-#pragma unroll
-  for (int s = 0; s < NSUB; s++) {
-    acc01[s] = tempo_div_const2(acc01[s], tempo_splat(dr[s].x), tempo_splat(dr[s].y));
-    acc23[s] = tempo_div_const2(acc23[s], tempo_splat(dr[s].x), tempo_splat(dr[s].y));
-    const f32x2 t = acc01[s] + acc23[s];
-    const float u = t.x + t.y;
-    odd |= u != u;
-  }
-  if (a.cmask != nullptr) {
-    unsigned long long* mw =
-        a.cmask + ((long long)b * ((a.N + kWaveVox - 1) / kWaveVox) + (n0 >> 6)) * mask_words(L);
-#pragma unroll
-    for (int s = 0; s < NSUB; s++) {
-      const bool live_el = lane_on && s * VPS + vq < kWaveVox;
-      const float e[4] = {acc01[s].x, acc01[s].y, acc23[s].x, acc23[s].y};
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const unsigned long long bal =
-            __builtin_amdgcn_ballot_w64(live_el && e[j] >= 0.0f && e[j] <= 1.0f);
-        if (lane == 0) mw[s * 4 + j] = bal;
-      }
-    }
-  }
-  const bool slow = __builtin_amdgcn_ballot_w64(odd) != 0;
-#pragma unroll
-  for (int s = 0; s < NSUB; s++) {
-    const int vsl = s * VPS + vq;
-    if (lane_on && vsl < kWaveVox) {
-      float* o = s_out + (4 * cq) * TSTR + vsl;
-      if (!slow) {
-        o[0 * TSTR] = __builtin_amdgcn_fmed3f(acc01[s].x, 0.0f, 1.0f);
-        o[1 * TSTR] = __builtin_amdgcn_fmed3f(acc01[s].y, 0.0f, 1.0f);
-        o[2 * TSTR] = __builtin_amdgcn_fmed3f(acc23[s].x, 0.0f, 1.0f);
-        o[3 * TSTR] = __builtin_amdgcn_fmed3f(acc23[s].y, 0.0f, 1.0f);
-      } else {
-        o[0 * TSTR] = tempo_nan_clamp(acc01[s].x, 0.0f, 1.0f);
-        o[1 * TSTR] = tempo_nan_clamp(acc01[s].y, 0.0f, 1.0f);
-        o[2 * TSTR] = tempo_nan_clamp(acc23[s].x, 0.0f, 1.0f);
-        o[3 * TSTR] = tempo_nan_clamp(acc23[s].y, 0.0f, 1.0f);
-      }
-    }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  if (n < a.N && a.cubes != nullptr) {
-    float* dst = a.cubes + (long long)b * a.C * a.N + n;
-    for (int ch = 0; ch < a.C; ch++) dst[(long long)ch * a.N] = s_out[ch * TSTR + lane];
-  }
-  if (a.pl01 != nullptr || a.pl02 != nullptr || a.pl12 != nullptr)
-    planes_epilogue(a, b, n0, lane, s_out, TSTR);
-}
-
-// -------------------------------------------- window forward, texels staged in LDS
-// The fine lattice's voxels are 1-2 heatmap pixels apart, so the 2x2 footprints of
-// neighbouring voxels overlap heavily, yet unproject_kernel<WINDOW> moves every sample's
-// four texels (4 x CP x 4 bytes) through the texture path on its own: that path (about 57
-// bytes per clock and CU) is what bounds it.  Here one wave (= one workgroup) owns a brick
-// of 4 x 4 x 4 voxels.  Per view it projects its voxels (lane = voxel, the arithmetic of
-// unproject_kernel's phase A), takes the bounding box of their footprints (four DPP wave
-// maxima) and -- if the box holds at most kFwdCap texels -- copies the box once from the map
-// into a wave-private LDS tile with full-width coalesced loads (lane = 16-byte piece of the
-// box in row-major order), then every lane mixes its four texels out of LDS.  A box that
-// does not fit (a camera much closer than usual) is sampled straight from memory.  The
-// per-voxel operations and their order are those of unproject_kernel: results are
-// bit-identical.
-#ifndef TEMPO_FWD_CAP
-#define TEMPO_FWD_CAP 96
-#endif
-constexpr int kFwdCap = TEMPO_FWD_CAP;  // texels per tile
-
-constexpr int kFwdWaves = 4;  // bricks (waves) per workgroup, consecutive along z
-// LDS per workgroup: one tile per wave; the output staging [CP][16 columns][16 z] reuses it
-constexpr int fwd_brick_lds(int L) {
-  const int tiles = kFwdWaves * kFwdCap * L * 16;
-  const int stage = 4 * L * kBrickEdge * kBrickEdge * (kFwdWaves * kBrickEdge) * 4;
-  return tiles > stage ? tiles : stage;
-}
-
-template <int L, int UNF>
-__global__ __launch_bounds__(kFwdWaves * 64) void window_brick_kernel(const UnprojArgs a) {
-  constexpr int MODE = MODE_WINDOW;
-  constexpr int CAP = kFwdCap;
-  constexpr int KMAX = (CAP * L + 63) / 64;  // 16-byte pieces of a full tile per lane
-  constexpr int ZR = kFwdWaves * kBrickEdge;  // z extent of a workgroup: 16 voxels = 64 bytes
-  extern __shared__ __align__(16) unsigned char smem[];
-
-  const int bid = blockIdx.x;
-  const int run = bid >> 3;
-  const int item = (bid & 7) * a.chunk + run;  // XCD-aware order, as unproject_kernel
-  if (run >= a.chunk || item >= a.total) return;
-  const int b = __builtin_amdgcn_readfirstlane(item / a.tiles);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  u32x4* tile = reinterpret_cast<u32x4*>(smem) + wave * (CAP * L);  // [CAP texels][L quads]
-  int frame = b;
-  if (a.win_frame != nullptr) frame = uniform_load(a.win_frame, b);
-  const bool dead = (a.live != nullptr && uniform_load_u8(a.live, b) == 0) ||
-                    (unsigned)frame >= (unsigned)a.F;
-
-  // workgroup = 4 x 4 x 16 voxels: four bricks along z, one per wave
-  const int nb1 = (a.dim[1] + kBrickEdge - 1) / kBrickEdge;
-  const int nb2 = (a.dim[2] + ZR - 1) / ZR;
-  const int group = item - b * a.tiles;
-  const int bx = __builtin_amdgcn_readfirstlane(group / (nb1 * nb2));
-  const int by = __builtin_amdgcn_readfirstlane((group - bx * nb1 * nb2) / nb2);
-  const int bz = group - (bx * nb1 + by) * nb2;
-  const int i0 = bx * kBrickEdge + (lane >> 4);
-  const int i1 = by * kBrickEdge + ((lane >> 2) & 3);
-  const int i2 = bz * ZR + wave * kBrickEdge + (lane & 3);
-  const bool inb = i0 < a.dim[0] && i1 < a.dim[1] && i2 < a.dim[2];
-  const int n = (i0 * a.dim[1] + i1) * a.dim[2] + i2;
-
-  float x = 0.f, y = 0.f, z = 0.f;
-  const bool have = !dead && inb && voxel_world<MODE>(a, b, n, &x, &y, &z);
-  const bool any = __builtin_amdgcn_ballot_w64(have) != 0;  // wave-uniform
-  asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
-
-  f32x2 acc01[L], acc23[L];
-#pragma unroll
-  for (int q = 0; q < L; q++) {
-    acc01[q] = tempo_splat(0.f);
-    acc23[q] = tempo_splat(0.f);
-  }
-  const unsigned tb = (unsigned)a.texel_bytes, rowb = (unsigned)a.row_bytes;
-
-  auto mix4 = [&](int q, const u32x4& ta, const u32x4& tb4, const u32x4& tc, const u32x4& td,
-                  float nwf, float nef, float swf, float sef) {
-    const f32x2 nw = tempo_splat(nwf), ne = tempo_splat(nef);
-    const f32x2 sw = tempo_splat(swf), se = tempo_splat(sef);
-    const f32x2 a01 = {__uint_as_float(ta[0]), __uint_as_float(ta[1])};
-    const f32x2 a23 = {__uint_as_float(ta[2]), __uint_as_float(ta[3])};
-    const f32x2 b01 = {__uint_as_float(tb4[0]), __uint_as_float(tb4[1])};
-    const f32x2 b23 = {__uint_as_float(tb4[2]), __uint_as_float(tb4[3])};
-    const f32x2 c01 = {__uint_as_float(tc[0]), __uint_as_float(tc[1])};
-    const f32x2 c23 = {__uint_as_float(tc[2]), __uint_as_float(tc[3])};
-    const f32x2 d01 = {__uint_as_float(td[0]), __uint_as_float(td[1])};
-    const f32x2 d23 = {__uint_as_float(td[2]), __uint_as_float(td[3])};
-    f32x2 v01 = a01 * nw, v23 = a23 * nw;
-    v01 = __builtin_elementwise_fma(b01, ne, v01);
-    v23 = __builtin_elementwise_fma(b23, ne, v23);
-    v01 = __builtin_elementwise_fma(c01, sw, v01);
-    v23 = __builtin_elementwise_fma(c23, sw, v23);
-    v01 = __builtin_elementwise_fma(d01, se, v01);
-    v23 = __builtin_elementwise_fma(d23, se, v23);
-    acc01[q] = acc01[q] + v01;
-    acc23[q] = acc23[q] + v23;
-  };
-
-  if (any) {
-#pragma unroll 1
-    for (int slot = 0; slot < a.V; slot++) {
-      const int view = slot_view(a, slot);
-      const TempoCam cam = load_cam(a.cam, frame * a.V + view);
-      const __amdgpu_buffer_rsrc_t rs = map_rsrc(a, frame, view, true);
-      TempoPix p;
-      p.px = p.py = 0.f;
-      p.inside = 0;
-      if (have) p = tempo_world_to_pixel(&cam, x, y, z, UNF);
-      float gx, gy;
-      tempo_pixel_to_grid(&cam, p.px, p.py, &a.geom, UNF, &gx, &gy);
-      const TempoTap t = tempo_bilinear_tap(gx, gy, a.W, a.H);
-      // footprint box of the brick (|x0|, |y0| < 2^15: host-checked map size, and the
-      // sample grid is clamped to +-1.1; a NaN sample point has x0 = y0 = 0, NaN weights)
-      const unsigned k0 = wave_umax_to_lane63(have ? (unsigned)(32767 - t.x0) : 0u);
-      const unsigned k1 = wave_umax_to_lane63(have ? (unsigned)(32767 - t.y0) : 0u);
-      const unsigned k2 = wave_umax_to_lane63(have ? (unsigned)(t.x0 + 32768) : 0u);
-      const unsigned k3 = wave_umax_to_lane63(have ? (unsigned)(t.y0 + 32768) : 0u);
-      const int ox = 32767 - __builtin_amdgcn_readlane((int)k0, 63);
-      const int oy = 32767 - __builtin_amdgcn_readlane((int)k1, 63);
-      const int bw = __builtin_amdgcn_readlane((int)k2, 63) - 32768 + 2 - ox;
-      const int bh = __builtin_amdgcn_readlane((int)k3, 63) - 32768 + 2 - oy;
-      const bool fits = bw <= CAP && bh <= CAP && bw * bh <= CAP;  // wave-uniform
-      if (fits) {
-        // ---- copy the box: piece i = (texel ty * bw + tx, quad q), row-major
-        const int pieces = bw * bh * L;
-        const float rbw = 1.0f / (float)bw;
-        u32x4 pc[KMAX];
-#pragma unroll
-        for (int k = 0; k < KMAX; k++) {
-          if (k * 64 < pieces) {  // wave-uniform
-            const int i = k * 64 + lane;
-            const int tt = i / L, q = i - tt * L;
-            // tt / bw for small non-negative integers: the quotient's fractional part is
-            // at least 0.5 / bw away from an integer
-            const int ty = (int)(((float)tt + 0.5f) * rbw);
-            const int tx = tt - ty * bw;
-            const int mx = ox + tx, my = oy + ty;
-            unsigned off = kInvalid;  // columns outside the map: zeros; rows: the range check
-            if (i < pieces && (unsigned)mx < (unsigned)a.W)
-              off = (unsigned)texel_offset(my, mx, a.row_bytes, a.texel_bytes) +
-                    (unsigned)q * 16u;
-            pc[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int k = 0; k < KMAX; k++) {
-          const int i = k * 64 + lane;
-          if (k * 64 < pieces && i < CAP * L) tile[i] = pc[k];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (have) {
-          const int base = ((t.y0 - oy) * bw + (t.x0 - ox)) * L;
-          const int down = bw * L;
-#pragma unroll
-          for (int q = 0; q < L; q++)
-            mix4(q, tile[base + q], tile[base + L + q], tile[base + down + q],
-                 tile[base + down + L + q], t.nw, t.ne, t.sw, t.se);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      } else {
-        // ---- straight from memory, lane = voxel
-        const bool x0ok = have && (unsigned)t.x0 < (unsigned)a.W;
-        const bool x1ok = have && (unsigned)(t.x0 + 1) < (unsigned)a.W;
-        const unsigned base = (unsigned)texel_offset(t.y0, t.x0, a.row_bytes, a.texel_bytes);
-        const unsigned oa = x0ok ? base : kInvalid, ob = x1ok ? base + tb : kInvalid;
-#pragma unroll
-        for (int q = 0; q < L; q++) {
-          const unsigned lo = (unsigned)q * 16u;
-          const u32x4 ta = __builtin_amdgcn_raw_buffer_load_b128(rs, oa + lo, 0, 0);
-          const u32x4 tb4 = __builtin_amdgcn_raw_buffer_load_b128(rs, ob + lo, 0, 0);
-          const u32x4 tc = __builtin_amdgcn_raw_buffer_load_b128(rs, oa + rowb + lo, 0, 0);
-          const u32x4 td = __builtin_amdgcn_raw_buffer_load_b128(rs, ob + rowb + lo, 0, 0);
-          if (have) mix4(q, ta, tb4, tc, td, t.nw, t.ne, t.sw, t.se);
-        }
-      }
-    }
-  }
-
-  // ---- mean over the V views (no bounds mask in the window variant), clamp; the four
-  // bricks of the workgroup meet in LDS so that every store covers whole 64-byte runs
-  // along z (16-byte runs per brick cost four times the write requests)
-  __syncthreads();  // all waves are done with their tiles
-  float* stage = reinterpret_cast<float*>(smem);  // [4L channels][16 columns][ZR]
-  {
-    const float den = (float)a.V + 1e-6f;
-    const f32x2 d2 = tempo_splat(den), r2 = tempo_splat(1.0f / den);
-    const int col = lane >> 2, zz = wave * kBrickEdge + (lane & 3);
-#pragma unroll
-    for (int q = 0; q < L; q++) {
-      const f32x2 v01 = tempo_div_const2(acc01[q], d2, r2);
-      const f32x2 v23 = tempo_div_const2(acc23[q], d2, r2);
-      const float e[4] = {v01.x, v01.y, v23.x, v23.y};
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        stage[((4 * q + j) * 16 + col) * ZR + zz] =
-            have ? tempo_nan_clamp(e[j], 0.0f, 1.0f) : 0.0f;
-    }
-  }
-  __syncthreads();
-  {
-    const int zz = tid & (ZR - 1), col = tid >> 4;  // 256 threads = 16 columns x 16 z
-    const int o0 = bx * kBrickEdge + (col >> 2), o1 = by * kBrickEdge + (col & 3);
-    const int o2 = bz * ZR + zz;
-    if (o0 < a.dim[0] && o1 < a.dim[1] && o2 < a.dim[2]) {
-      float* dst = a.cubes + (long long)b * a.C * a.N + ((long long)o0 * a.dim[1] + o1) * a.dim[2] + o2;
-      for (int ch = 0; ch < a.C; ch++) dst[(long long)ch * a.N] = stage[(ch * 16 + col) * ZR + zz];
-    }
-  }
-}
-
-template <int L, int UNF>
-int launch_window_brick(const UnprojArgs& a, hipStream_t stream) {
-  UnprojArgs k = a;
-  fill_order_magic(k.order, k.magic, a.V, a.dim);
-  const long long groups = (long long)((a.dim[0] + kBrickEdge - 1) / kBrickEdge) *
-                           ((a.dim[1] + kBrickEdge - 1) / kBrickEdge) *
-                           ((a.dim[2] + kFwdWaves * kBrickEdge - 1) / (kFwdWaves * kBrickEdge));
-  const long long total = (long long)a.NB * groups;
-  if (total > 0x7fffffffLL / 8) return TEMPO_E_DIM;
-  k.tile_vox = kFwdWaves * kWaveVox;
-  k.tiles = (int)groups;
-  k.total = (int)total;
-  k.chunk = (k.total + 7) / 8;
-  hipLaunchKernelGGL((window_brick_kernel<L, UNF>), dim3(8 * k.chunk), dim3(kFwdWaves * 64),
-                     (size_t)fwd_brick_lds(L), stream, k);
-  return (int)hipGetLastError();
-}
-
 // ------------------------------------------------------------------ backward
 // Gradient of the volume with respect to the heatmaps (the only input with a
 // gradient: cameras and grids are constants).  Mirrors autograd through the
@@ -2281,15 +1688,7 @@ int launch_one(const UnprojArgs& a, hipStream_t stream) {
   constexpr int SB = MODE == MODE_ROOT ? (L == 4 ? TEMPO_SB_ROOT : 2)
                                        : (L >= 7 ? 2 : TEMPO_SB_WINDOW);
   UnprojArgs k = a;
-  for (int i = 0; i < 2; i++) {
-    const unsigned long long m = 0x100000000ULL / (unsigned)a.dim[2 - i];
-    k.magic[i] = m > 0xffffffffULL ? 0xffffffffu : (unsigned)m;
-  }
-  for (int w = 0; w < 10; w++) k.order[w] = 0xffffffffu;
-  for (int sl = 0; sl < a.V; sl++) {
-    const unsigned v = (unsigned)tempo_view_of_slot(sl, a.V);
-    k.order[sl >> 2] = (k.order[sl >> 2] & ~(255u << ((sl & 3) * 8))) | (v << ((sl & 3) * 8));
-  }
+  fill_order_magic(k.order, k.magic, a.V, a.dim);
   const int waves = kThreads / 64;
   k.tile_vox = waves * kWaveVox;
   k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
@@ -2331,15 +1730,7 @@ int launch_one(const UnprojArgs& a, hipStream_t stream) {
 template <int MODE, int L, int UNF>
 int launch_backward_one(const UnprojArgs& a, hipStream_t stream) {
   UnprojArgs k = a;
-  for (int i = 0; i < 2; i++) {
-    const unsigned long long m = 0x100000000ULL / (unsigned)a.dim[2 - i];
-    k.magic[i] = m > 0xffffffffULL ? 0xffffffffu : (unsigned)m;
-  }
-  for (int w = 0; w < 10; w++) k.order[w] = 0xffffffffu;
-  for (int sl = 0; sl < a.V; sl++) {
-    const unsigned v = (unsigned)tempo_view_of_slot(sl, a.V);
-    k.order[sl >> 2] = (k.order[sl >> 2] & ~(255u << ((sl & 3) * 8))) | (v << ((sl & 3) * 8));
-  }
+  fill_order_magic(k.order, k.magic, a.V, a.dim);
   const int waves = kThreads / 64;
   k.tile_vox = waves * kWaveVox;
   k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
@@ -2369,15 +1760,7 @@ int launch_backward_one(const UnprojArgs& a, hipStream_t stream) {
 template <int L, int UNF>
 int launch_backward_brick(const UnprojArgs& a, hipStream_t stream) {
   UnprojArgs k = a;
-  for (int i = 0; i < 2; i++) {
-    const unsigned long long m = 0x100000000ULL / (unsigned)a.dim[2 - i];
-    k.magic[i] = m > 0xffffffffULL ? 0xffffffffu : (unsigned)m;
-  }
-  for (int w = 0; w < 10; w++) k.order[w] = 0xffffffffu;
-  for (int sl = 0; sl < a.V; sl++) {
-    const unsigned v = (unsigned)tempo_view_of_slot(sl, a.V);
-    k.order[sl >> 2] = (k.order[sl >> 2] & ~(255u << ((sl & 3) * 8))) | (v << ((sl & 3) * 8));
-  }
+  fill_order_magic(k.order, k.magic, a.V, a.dim);
   const long long bricks = (long long)((a.dim[0] + kBrickEdge - 1) / kBrickEdge) *
                            ((a.dim[1] + kBrickEdge - 1) / kBrickEdge) *
                            ((a.dim[2] + kBrickEdge - 1) / kBrickEdge);
@@ -2449,37 +1832,6 @@ int launch_mode(const UnprojArgs& a, int mm_unfused, hipStream_t stream) {
   return TEMPO_E_ARG;
 }
 
-template <int MODE, int L>
-int launch_gather_l(const UnprojArgs& a, hipStream_t stream) {
-  UnprojArgs k = a;
-  fill_order_magic(k.order, k.magic, a.V, a.dim);
-  // four waves per workgroup while their records fit 64 KB of LDS, else one
-  k.wave_lds = gather_wave_lds(a.V, L);
-  const int waves = 4 * k.wave_lds <= 65536 ? 4 : 1;
-  if (waves * k.wave_lds > 65536) return TEMPO_E_DIM;
-  k.tile_vox = waves * kWaveVox;
-  k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
-  const long long total = (long long)a.NB * k.tiles;
-  if (total > 0x7fffffffLL / 8) return TEMPO_E_DIM;
-  k.total = (int)total;
-  k.chunk = (k.total + 7) / 8;
-  hipLaunchKernelGGL((gather_kernel<MODE, L>), dim3(8 * k.chunk), dim3(waves * 64),
-                     (size_t)waves * k.wave_lds, stream, k);
-  return (int)hipGetLastError();
-}
-
-template <int MODE>
-int launch_gather(const UnprojArgs& a, hipStream_t stream) {
-  switch (a.CP / 4) {
-    case 4: return launch_gather_l<MODE, 4>(a, stream);
-    case 5: return launch_gather_l<MODE, 5>(a, stream);
-    case 6: return launch_gather_l<MODE, 6>(a, stream);
-    case 7: return launch_gather_l<MODE, 7>(a, stream);
-    case 8: return launch_gather_l<MODE, 8>(a, stream);
-    default: return TEMPO_E_PAD;
-  }
-}
-
 // 16-byte alignment of a device pointer the kernels access with 128-bit loads / stores
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -2496,10 +1848,6 @@ struct Extra {
   float* zmax = nullptr;                // root forward: max over z, [B][C][X][Y]
   unsigned long long* cmask = nullptr;  // forward: record / backward: read the clamp mask
   float* ghm = nullptr;                 // backward: gradient of the heatmaps (accumulated)
-  // gather kernels: footprint table instead of per-frame camera records
-  const uint32_t* table = nullptr;
-  const int32_t* cal_of = nullptr;
-  int NC = 0;
 };
 
 // Where the heatmaps are: `hm` = the repacked [F][V][H][W][CP] buffer (all kernels), or
@@ -2805,10 +2153,7 @@ int root_impl(const Layout& lay, const float* cam, const float* ax_x, const floa
               int W, int X, int Y, int Z, float hm_w, float hm_h, float img_w, float img_h,
               int mm_unfused, const int32_t* groups, int num_groups, const Extra& ex,
               void* stream) {
-  const bool tab = ex.table != nullptr;
-  if ((!tab && !cam) || !cubes) return TEMPO_E_NULL;
-  // the axes are only read to project (no table) or to write `grids`
-  if ((!tab || grids) && (!ax_x || !ax_y || !ax_z)) return TEMPO_E_NULL;
+  if (!cam || !ax_x || !ax_y || !ax_z || !cubes) return TEMPO_E_NULL;
   if ((groups == nullptr) != (num_groups == 0) || num_groups < 0 || num_groups > B)
     return TEMPO_E_ARG;
   const int rc = check_common(V, C, CP, H, W);
@@ -2821,11 +2166,8 @@ int root_impl(const Layout& lay, const float* cam, const float* ax_x, const floa
                 mask_bytes == 4))
     return TEMPO_E_ARG;
   if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
-  // the grouped launch, the training forward's consumers and the backward work on the
-  // repacked buffer only; the table carries no per-item axes
+  // the grouped launch and the backward work on the repacked buffer only
   if (lay.hm == nullptr && (groups != nullptr || ex.ghm != nullptr)) return TEMPO_E_ARG;
-  if (tab && (groups != nullptr || ex.ghm != nullptr || ax_batched || ex.NC <= 0))
-    return TEMPO_E_ARG;
   UnprojArgs a = {};
   a.cam = cam;
   a.ax[0] = ax_x; a.ax[1] = ax_y; a.ax[2] = ax_z;
@@ -2855,12 +2197,6 @@ int root_impl(const Layout& lay, const float* cam, const float* ax_x, const floa
                                         (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     a.pl01 = reinterpret_cast<unsigned*>(ex.zmax);
-  }
-  if (tab) {
-    a.table = ex.table; a.cal_of = ex.cal_of; a.NC = ex.NC;
-    a.lat_n = N;
-    a.cal_words = N * (3LL * V + 1);
-    return launch_gather<MODE_ROOT>(a, (hipStream_t)stream);
   }
   return launch_mode<MODE_ROOT>(a, mm_unfused, (hipStream_t)stream);
 }
@@ -2977,80 +2313,7 @@ int tempo_root_step_static(const void* const* views, int C_total, int c_begin,
                          img_w, img_h, mm_unfused, ws, chunk, stream);
 }
 
-// ------------------------------------------- footprint table and gather entry points
-long long tempo_footprint_words(int V, long long lattice_points) {
-  if (V <= 0 || V > TEMPO_MAX_VIEWS || lattice_points <= 0) return TEMPO_E_DIM;
-  return lattice_points * (3LL * V + 1);
-}
-
-int tempo_project_footprints(const float* cam_cal, const float* ax_x, const float* ax_y,
-                             const float* ax_z, int NC, int V, int X, int Y, int Z, int H,
-                             int W, int texel_bytes, float hm_w, float hm_h, float img_w,
-                             float img_h, int mm_unfused, int window_mode, uint32_t* table,
-                             void* stream) {
-  if (!cam_cal || !ax_x || !ax_y || !ax_z || !table) return TEMPO_E_NULL;
-  if (NC <= 0 || NC > 65535 || V <= 0 || V > TEMPO_MAX_VIEWS || X <= 0 || Y <= 0 || Z <= 0 ||
-      H <= 0 || W <= 0)
-    return TEMPO_E_DIM;
-  if (texel_bytes <= 0 || texel_bytes % 4 != 0) return TEMPO_E_ARG;
-  if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
-  const long long N = (long long)X * Y * Z;
-  const long long row = (long long)W * texel_bytes;
-  if (N >= 0x7fffffffLL || H * row >= 0x80000000LL || row >= (1 << 23) || H >= (1 << 23))
-    return TEMPO_E_SIZE;
-  FootArgs a = {};
-  a.cam = cam_cal;
-  a.ax[0] = ax_x; a.ax[1] = ax_y; a.ax[2] = ax_z;
-  a.table = table;
-  a.lat_n = N;
-  a.cal_words = N * (3LL * V + 1);
-  a.dim[0] = X; a.dim[1] = Y; a.dim[2] = Z;
-  a.V = V; a.H = H; a.W = W; a.texel_bytes = texel_bytes; a.row_bytes = (int)row;
-  fill_order_magic(a.order, a.magic, V, a.dim);
-  a.geom = tempo_make_geom(hm_w, hm_h, img_w, img_h);
-  const dim3 grid((unsigned)((N + kThreads - 1) / kThreads), (unsigned)NC);
-  hipStream_t st = (hipStream_t)stream;
-  if (window_mode) {
-    if (mm_unfused) hipLaunchKernelGGL((footprint_kernel<MODE_WINDOW, 1>), grid, dim3(kThreads), 0, st, a);
-    else hipLaunchKernelGGL((footprint_kernel<MODE_WINDOW, 0>), grid, dim3(kThreads), 0, st, a);
-  } else {
-    if (mm_unfused) hipLaunchKernelGGL((footprint_kernel<MODE_ROOT, 1>), grid, dim3(kThreads), 0, st, a);
-    else hipLaunchKernelGGL((footprint_kernel<MODE_ROOT, 0>), grid, dim3(kThreads), 0, st, a);
-  }
-  return (int)hipGetLastError();
-}
-
-int tempo_gather_root(const void* const* views, long long frame_bytes, int texel_bytes,
-                      const uint32_t* table, const int32_t* cal_of, int NC,
-                      const float* ax_x, const float* ax_y, const float* ax_z,
-                      const uint8_t* live, float* cubes, float* grids, void* mask,
-                      int mask_bytes, float* zmax, int B, int V, int C, int CP, int H, int W,
-                      int X, int Y, int Z, void* stream) {
-  if (!views || !table) return TEMPO_E_NULL;
-  Layout lay;
-  lay.views = views; lay.frame_bytes = frame_bytes; lay.texel_bytes = texel_bytes;
-  Extra ex;
-  ex.table = table; ex.cal_of = cal_of; ex.NC = NC; ex.zmax = zmax;
-  return root_impl(lay, nullptr, ax_x, ax_y, ax_z, 0, live, cubes, grids, mask, mask_bytes, B, V,
-                   C, CP, H, W, X, Y, Z, 1.0f, 1.0f, 1.0f, 1.0f, 0, nullptr, 0, ex, stream);
-}
-
-int tempo_gather_window(const void* const* views, long long frame_bytes, int texel_bytes,
-                        const uint32_t* table, const int32_t* cal_of, int NC,
-                        const int32_t* win_frame, const int32_t* tl, const int32_t* start,
-                        const int32_t* end, const uint8_t* live, float* cubes, int NW, int F,
-                        int V, int C, int CP, int H, int W, int FX, int FY, int FZ, int VX,
-                        int VY, int VZ, void* stream) {
-  if (!views || !table || !cubes) return TEMPO_E_NULL;
-  Layout lay;
-  lay.views = views; lay.frame_bytes = frame_bytes; lay.texel_bytes = texel_bytes;
-  Extra ex;
-  ex.table = table; ex.cal_of = cal_of; ex.NC = NC;
-  return window_impl(lay, nullptr, win_frame, nullptr, nullptr, nullptr, tl, start, end, live,
-                     cubes, nullptr, nullptr, nullptr, NW, F, V, C, CP, H, W, FX, FY, FZ, VX, VY,
-                     VZ, 1.0f, 1.0f, 1.0f, 1.0f, 0, nullptr, 0, ex, stream);
-}
-
+// ------------------------------------------- heatmaps read in place (channel-last views)
 int tempo_unproject_root_views(const void* const* views, long long frame_bytes,
                                int texel_bytes, const float* cam, const float* ax_x,
                                const float* ax_y, const float* ax_z, int ax_batched,
@@ -3080,46 +2343,6 @@ int tempo_unproject_window_views(const void* const* views, long long frame_bytes
   return window_impl(lay, cam, win_frame, fx, fy, fz, tl, start, end, live, cubes, nullptr,
                      nullptr, nullptr, NW, F, V, C, CP, H, W, FX, FY, FZ, VX, VY, VZ, hm_w, hm_h,
                      img_w, img_h, mm_unfused, nullptr, 0, Extra(), stream);
-}
-
-int tempo_root_step_shared(const void* const* views, int C_total, int c_begin,
-                           const float* cam_cal, int NC, const int32_t* cal_of,
-                           const float* ax_x, const float* ax_y, const float* ax_z,
-                           const uint8_t* live, float* cubes, float* grids, void* mask,
-                           int mask_bytes, int B, int V, int C, int CP, int H, int W, int X,
-                           int Y, int Z, float hm_w, float hm_h, float img_w, float img_h,
-                           int mm_unfused, uint32_t* table, float* workspace, int chunk,
-                           void* stream) {
-  if (!views || !workspace || !cam_cal || !cubes || !table) return TEMPO_E_NULL;
-  const int rc = check_common(V, C, CP, H, W);
-  if (rc != TEMPO_OK) return rc;
-  if (B <= 0 || B > 65535 || chunk <= 0 || c_begin < 0 || c_begin + C > C_total || X <= 0 ||
-      Y <= 0 || Z <= 0 || NC <= 0)
-    return TEMPO_E_DIM;
-  if (!aligned16(workspace)) return TEMPO_E_ARG;
-  for (int v = 0; v < V; v++)
-    if (views[v] == nullptr) return TEMPO_E_NULL;
-  int err = tempo_project_footprints(cam_cal, ax_x, ax_y, ax_z, NC, V, X, Y, Z, H, W, CP * 4,
-                                     hm_w, hm_h, img_w, img_h, mm_unfused, 0, table, stream);
-  const long long HW = (long long)H * W;
-  const long long N = (long long)X * Y * Z;
-  const void* shifted[TEMPO_MAX_VIEWS];
-  Extra ex;
-  ex.table = table; ex.NC = NC;
-  for (int b0 = 0; b0 < B && err == TEMPO_OK; b0 += chunk) {
-    const int n = b0 + chunk <= B ? chunk : B - b0;
-    for (int v = 0; v < V; v++)
-      shifted[v] = static_cast<const float*>(views[v]) + (long long)b0 * C_total * HW;
-    err = tempo_repack_nhwc(shifted, V, n, C_total, c_begin, C, H, W, CP, workspace, stream);
-    if (err != TEMPO_OK) break;
-    ex.cal_of = cal_of ? cal_of + b0 : nullptr;
-    err = root_impl(workspace, nullptr, ax_x, ax_y, ax_z, 0, live ? live + b0 : nullptr,
-                    cubes + (long long)b0 * C * N, grids ? grids + (long long)b0 * N * 3 : nullptr,
-                    mask ? static_cast<char*>(mask) + (long long)b0 * N * mask_bytes : nullptr,
-                    mask_bytes, n, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w, img_h, mm_unfused,
-                    nullptr, 0, ex, stream);
-  }
-  return err;
 }
 
 int tempo_unproject_window(const float* hm, const float* cam, const int32_t* win_frame,
@@ -3176,9 +2399,7 @@ int window_impl(const Layout& lay, const float* cam, const int32_t* win_frame, c
                 int W, int FX, int FY, int FZ, int VX, int VY, int VZ, float hm_w, float hm_h,
                 float img_w, float img_h, int mm_unfused, const int32_t* groups,
                 int num_groups, const Extra& ex, void* stream) {
-  const bool tab = ex.table != nullptr;
-  if (!tl || !start || !end) return TEMPO_E_NULL;
-  if (!tab && (!cam || !fx || !fy || !fz)) return TEMPO_E_NULL;
+  if (!cam || !fx || !fy || !fz || !tl || !start || !end) return TEMPO_E_NULL;
   if ((groups == nullptr) != (num_groups == 0) || num_groups < 0 || num_groups > NW)
     return TEMPO_E_ARG;
   const int rc = check_common(V, C, CP, H, W);
@@ -3190,8 +2411,6 @@ int window_impl(const Layout& lay, const float* cam, const int32_t* win_frame, c
   if (N * 4 >= 0x80000000LL) return TEMPO_E_SIZE;
   if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
   if (lay.hm == nullptr && (groups != nullptr || ex.ghm != nullptr)) return TEMPO_E_ARG;
-  if (tab && (groups != nullptr || ex.ghm != nullptr || ex.NC <= 0 || plane_xz || plane_yz))
-    return TEMPO_E_ARG;
   UnprojArgs a = {};
   a.cam = cam;
   a.ax[0] = fx; a.ax[1] = fy; a.ax[2] = fz;
@@ -3225,36 +2444,6 @@ int window_impl(const Layout& lay, const float* cam, const int32_t* win_frame, c
                                         (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     return launch_backward<MODE_WINDOW>(a, mm_unfused, (hipStream_t)stream);
-  }
-  if (tab) {
-    if (!cubes) return TEMPO_E_NULL;
-    a.table = ex.table; a.cal_of = ex.cal_of; a.NC = ex.NC;
-    a.lat_n = (long long)FX * FY * FZ;
-    a.cal_words = a.lat_n * (3LL * V + 1);
-    return launch_gather<MODE_WINDOW>(a, (hipStream_t)stream);
-  }
-  // plain forward: the kernel that stages texel tiles in LDS (TEMPO_WINDOW_BRICK=0 in the
-  // environment selects unproject_kernel<WINDOW> instead, for A/B measurements)
-  static const bool brick_on = [] {
-    const char* e = getenv("TEMPO_WINDOW_BRICK");
-    return e == nullptr || e[0] != '0';
-  }();
-  if (brick_on && cubes != nullptr && groups == nullptr && ex.cmask == nullptr &&
-      plane_xy == nullptr && plane_xz == nullptr && plane_yz == nullptr && a.W <= 16384 &&
-      a.H <= 16384) {
-#define TEMPO_FWD_BRICK_CASE(LL)                                                 \
-  case LL:                                                                       \
-    return mm_unfused ? launch_window_brick<LL, 1>(a, (hipStream_t)stream)       \
-                      : launch_window_brick<LL, 0>(a, (hipStream_t)stream);
-    switch (a.CP / 4) {
-      TEMPO_FWD_BRICK_CASE(4)
-      TEMPO_FWD_BRICK_CASE(5)
-      TEMPO_FWD_BRICK_CASE(6)
-      TEMPO_FWD_BRICK_CASE(7)
-      TEMPO_FWD_BRICK_CASE(8)
-      default: return TEMPO_E_PAD;
-    }
-#undef TEMPO_FWD_BRICK_CASE
   }
   return launch_mode<MODE_WINDOW>(a, mm_unfused, (hipStream_t)stream);
 }

@@ -609,7 +609,7 @@ def project_points(pts, cam, heatmap_size, image_size, mm_mode='auto'):
 
 
 # --------------------------------------------------------------------------
-# heatmaps in place (channel-last tensors) and the footprint-table path
+# heatmaps read in place (channel-last tensors)
 # --------------------------------------------------------------------------
 
 class MapLayout:
@@ -658,168 +658,6 @@ def channels_last_layout(feature_maps, c_begin=0):
                              f'[{B},{C_total},{H},{W}] tensor')
     return MapLayout(list(feature_maps), [fm.data_ptr() + 4 * c_begin for fm in feature_maps],
                      H * W * C_total * 4, C_total * 4, (B, H, W))
-
-
-def calibrations(cam_cpu):
-    """Distinct calibrations of a packed CPU camera table ``[B,V,32]`` (bit-exact
-    comparison of a frame's V records): ``(cam_cal [NC,V,32] CPU, cal_of [B] int32 CPU)``."""
-    arr = cam_cpu.contiguous().numpy()
-    index, firsts, cal_of = {}, [], []
-    for b in range(arr.shape[0]):
-        key = arr[b].tobytes()
-        k = index.get(key)
-        if k is None:
-            k = index[key] = len(firsts)
-            firsts.append(b)
-        cal_of.append(k)
-    return cam_cpu[firsts].contiguous(), torch.tensor(cal_of, dtype=torch.int32)
-
-
-def footprint_words(V, lattice_points):
-    n = int(_lib.load().tempo_footprint_words(int(V), int(lattice_points)))
-    _lib.check(min(n, 0), 'tempo_footprint_words')
-    return n
-
-
-def project_footprints(cam_cal, axes, H, W, texel_bytes, heatmap_size, image_size,
-                       window_mode=False, mm_mode='auto', out=None):
-    """Footprint table of ``NC`` calibrations over the lattice spanned by ``axes``:
-    ``cam_cal [NC,V,32]`` -> int32 ``[NC, footprint_words(V, X*Y*Z)]`` (private layout).
-    The table is tied to the map geometry ``(H, W, texel_bytes)``."""
-    lib = _lib.load()
-    dev = cam_cal.device
-    _need(cam_cal, torch.float32, 'cam_cal')
-    if cam_cal.dim() != 3 or cam_cal.shape[-1] != 32:
-        raise ValueError('cam_cal must be [NC,V,32]')
-    NC, V = int(cam_cal.shape[0]), int(cam_cal.shape[1])
-    ax = [_need(a, torch.float32, 'axes', dev) for a in axes]
-    if any(a.dim() != 1 for a in ax):
-        raise ValueError('a footprint table needs shared axes [X], [Y], [Z]')
-    X, Y, Z = (int(a.numel()) for a in ax)
-    words = footprint_words(V, X * Y * Z)
-    if out is None:
-        out = torch.empty(NC, words, dtype=torch.int32, device=dev)
-    else:
-        _need(out, torch.int32, 'out', dev)
-        if out.numel() < NC * words:
-            raise ValueError('out is too small for the footprint table')
-    with torch.cuda.device(dev):
-        rc = lib.tempo_project_footprints(
-            _ptr(cam_cal), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), NC, V, X, Y, Z, int(H), int(W),
-            int(texel_bytes), float(heatmap_size[0]), float(heatmap_size[1]),
-            float(image_size[0]), float(image_size[1]), numerics.abi_flag(mm_mode),
-            int(bool(window_mode)), _ptr(out), _stream_ptr(dev))
-    _lib.check(rc, 'tempo_project_footprints')
-    return out
-
-
-def _cal_arg(cal_of, n_frames, dev):
-    if cal_of is None:
-        return None
-    _need(cal_of, torch.int32, 'cal_of', dev)
-    if cal_of.numel() != n_frames:
-        raise ValueError('cal_of must have one entry per frame')
-    return cal_of
-
-
-def gather_root(layout, table, num_cal, cube_size, channels, cal_of=None, axes=None, live=None,
-                want_grids=False, want_mask=False, out=None, grids_out=None, mask_out=None,
-                zmax_out=None):
-    """Root-grid unprojection from a footprint table (:func:`project_footprints` with the
-    grid's axes and this layout's ``H, W, texel_bytes``).  Returns ``(cubes, grids, mask)``."""
-    lib = _lib.load()
-    dev = layout.device
-    B, V, H, W = layout.F, layout.V, layout.H, layout.W
-    C = int(channels)
-    CP = padded_channels(C)
-    X, Y, Z = (int(v) for v in cube_size)
-    N = X * Y * Z
-    _need(table, torch.int32, 'table', dev)
-    if table.numel() < int(num_cal) * footprint_words(V, N):
-        raise ValueError('table is smaller than num_cal calibrations of this grid')
-    cal_of = _cal_arg(cal_of, B, dev)
-    if live is not None:
-        _need(live, torch.uint8, 'live', dev)
-        if live.numel() != B:
-            raise ValueError('live must have B entries')
-    if out is None:
-        out = torch.empty(B, C, X, Y, Z, dtype=torch.float32, device=dev)
-    else:
-        _need(out, torch.float32, 'out', dev)
-        if out.numel() != B * C * N:
-            raise ValueError('out has the wrong size')
-    grids, ax = None, [None, None, None]
-    if want_grids:
-        if axes is None:
-            raise ValueError('grids need the axes')
-        ax = [_need(a, torch.float32, 'axes', dev) for a in axes]
-        if tuple(int(a.numel()) for a in ax) != (X, Y, Z):
-            raise ValueError('axes do not match cube_size')
-        grids = grids_out if grids_out is not None else torch.empty(
-            B, N, 3, dtype=torch.float32, device=dev)
-        _need(grids, torch.float32, 'grids_out', dev)
-    mask, mask_bytes = None, 0
-    if want_mask:
-        mask_bytes, mdt = mask_dtype(V)
-        mask = mask_out if mask_out is not None else torch.empty(B, N, dtype=mdt, device=dev)
-        _need(mask, mdt, 'mask_out', dev)
-    if zmax_out is not None:
-        _need(zmax_out, torch.float32, 'zmax_out', dev)
-        if zmax_out.numel() != B * C * X * Y:
-            raise ValueError('zmax_out must be [B,C,X,Y]')
-    with torch.cuda.device(dev):
-        rc = lib.tempo_gather_root(
-            layout.ptrs, layout.frame_bytes, layout.texel_bytes, _ptr(table), _ptr(cal_of),
-            int(num_cal), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), _ptr(live), _ptr(out),
-            _ptr(grids), _ptr(mask), mask_bytes, _ptr(zmax_out), B, V, C, CP, H, W, X, Y, Z,
-            _stream_ptr(dev))
-    _lib.check(rc, 'tempo_gather_root')
-    return out, grids, mask
-
-
-def gather_window(layout, table, num_cal, fine_dims, tl, start, end, sub_cube, channels,
-                  cal_of=None, win_frame=None, live=None, out=None):
-    """Window unprojection from a footprint table of the fine lattice
-    (:func:`project_footprints` with the fine axes, ``window_mode=True``)."""
-    lib = _lib.load()
-    dev = layout.device
-    F_, V, H, W = layout.F, layout.V, layout.H, layout.W
-    C = int(channels)
-    CP = padded_channels(C)
-    FX, FY, FZ = (int(v) for v in fine_dims)
-    VX, VY, VZ = (int(v) for v in sub_cube)
-    NW = int(tl.shape[0])
-    for name, t in (('tl', tl), ('start', start), ('end', end)):
-        _need(t, torch.int32, name, dev)
-        if tuple(t.shape) != (NW, 3):
-            raise ValueError(f'{name} must be [{NW},3]')
-    _need(table, torch.int32, 'table', dev)
-    if table.numel() < int(num_cal) * footprint_words(V, FX * FY * FZ):
-        raise ValueError('table is smaller than num_cal calibrations of this lattice')
-    cal_of = _cal_arg(cal_of, F_, dev)
-    if win_frame is not None:
-        _need(win_frame, torch.int32, 'win_frame', dev)
-        if win_frame.numel() != NW:
-            raise ValueError('win_frame must have one entry per window')
-    elif NW != F_:
-        raise ValueError('without win_frame there must be one window per frame')
-    if live is not None:
-        _need(live, torch.uint8, 'live', dev)
-        if live.numel() != NW:
-            raise ValueError('live must have one entry per window')
-    if out is None:
-        out = torch.empty(NW, C, VX, VY, VZ, dtype=torch.float32, device=dev)
-    else:
-        _need(out, torch.float32, 'out', dev)
-        if out.numel() != NW * C * VX * VY * VZ:
-            raise ValueError('out has the wrong size')
-    with torch.cuda.device(dev):
-        rc = lib.tempo_gather_window(
-            layout.ptrs, layout.frame_bytes, layout.texel_bytes, _ptr(table), _ptr(cal_of),
-            int(num_cal), _ptr(win_frame), _ptr(tl), _ptr(start), _ptr(end), _ptr(live),
-            _ptr(out), NW, F_, V, C, CP, H, W, FX, FY, FZ, VX, VY, VZ, _stream_ptr(dev))
-    _lib.check(rc, 'tempo_gather_window')
-    return out
 
 
 def unproject_root_views(layout, cam, axes, channels, heatmap_size, image_size, live=None,
@@ -902,72 +740,6 @@ def unproject_window_views(layout, cam, fine_axes, tl, start, end, sub_cube, cha
             _stream_ptr(dev))
     _lib.check(rc, 'tempo_unproject_window_views')
     return out
-
-
-def root_step_shared(feature_maps, cam_cal, cal_of, axes, heatmap_size, image_size, c_begin=0,
-                     channels=None, live=None, want_grids=False, want_mask=False, out=None,
-                     mm_mode='auto', chunk=None, hm_buf=None, table=None):
-    """``tempo_root_step_shared``: the root step for a batch whose frames come from
-    ``NC = cam_cal.shape[0]`` calibrations and share one grid -- one projection per
-    calibration (:func:`project_footprints`), then per chunk of frames repack + gather.
-    ``cal_of`` int32 ``[B]`` (device) or None when NC == 1.  Bit-identical to
-    :func:`root_step`.  Returns ``(cubes, grids | None, mask | None)``."""
-    lib = _lib.load()
-    fm0 = feature_maps[0]
-    dev = fm0.device
-    B, C_total, H, W = fm0.shape
-    V = len(feature_maps)
-    C = C_total - c_begin if channels is None else channels
-    cp = padded_channels(C)
-    chunk = ROOT_CHUNK_FRAMES if chunk is None else int(chunk)
-    keep = []
-    for i, fm in enumerate(feature_maps):
-        if tuple(fm.shape) != (B, C_total, H, W):
-            raise ValueError('feature maps of all views must share one shape')
-        if fm.dtype != torch.float32:
-            fm = fm.float()
-        keep.append(_need(fm.contiguous(), torch.float32, f'feature_maps[{i}]', dev))
-    _need(cam_cal, torch.float32, 'cam_cal', dev)
-    NC = int(cam_cal.shape[0])
-    if tuple(cam_cal.shape) != (NC, V, 32):
-        raise ValueError(f'cam_cal must be [NC,{V},32]')
-    cal_of = _cal_arg(cal_of, B, dev)
-    if cal_of is None and NC != 1:
-        raise ValueError('cal_of is required with more than one calibration')
-    ax = [_need(a, torch.float32, 'axes', dev) for a in axes]
-    if any(a.dim() != 1 for a in ax):
-        raise ValueError('root_step_shared needs shared axes [X], [Y], [Z]')
-    X, Y, Z = (int(a.numel()) for a in ax)
-    N = X * Y * Z
-    if live is not None:
-        _need(live, torch.uint8, 'live', dev)
-        if live.numel() != B:
-            raise ValueError('live must have B entries')
-    if out is None:
-        out = torch.empty(B, C, X, Y, Z, dtype=torch.float32, device=dev)
-    _need(out, torch.float32, 'out', dev)
-    if out.numel() != B * C * N:
-        raise ValueError('out has the wrong size')
-    grids = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if want_grids else None
-    mask = torch.empty(B, N, dtype=mask_dtype(V)[1], device=dev) if want_mask else None
-    need = int(lib.tempo_root_step_workspace(B, V, H, W, cp, chunk))
-    if hm_buf is None or hm_buf.numel() < need:
-        hm_buf = torch.empty(need, dtype=torch.float32, device=dev)
-    words = NC * footprint_words(V, N)
-    if table is None or table.numel() < words:
-        table = torch.empty(words, dtype=torch.int32, device=dev)
-    _need(table, torch.int32, 'table', dev)
-    mask_bytes = 0 if mask is None else mask_dtype(V)[0]
-    ptrs = (ctypes.c_void_p * V)(*[fm.data_ptr() for fm in keep])
-    with torch.cuda.device(dev):
-        rc = lib.tempo_root_step_shared(
-            ptrs, C_total, c_begin, _ptr(cam_cal), NC, _ptr(cal_of), _ptr(ax[0]), _ptr(ax[1]),
-            _ptr(ax[2]), _ptr(live), _ptr(out), _ptr(grids), _ptr(mask), mask_bytes, B, V, C,
-            cp, H, W, X, Y, Z, float(heatmap_size[0]), float(heatmap_size[1]),
-            float(image_size[0]), float(image_size[1]), numerics.abi_flag(mm_mode),
-            _ptr(table), _ptr(hm_buf), int(chunk), _stream_ptr(dev))
-    _lib.check(rc, 'tempo_root_step_shared')
-    return out, grids, mask
 
 
 def gather_zcolumns(cubes, index, out=None):

@@ -1,0 +1,83 @@
+"""GPU parity of heatmaps read in place from channel-last tensors (no repack) and of the
+z-column gather, through the C ABI.  Bars: bit-identical to the repacked path (same
+operations, same order) / to the detector's torch.gather."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _canon(t):
+    return torch.nan_to_num(t.float(), nan=-7777.0)
+
+
+def _axes(cfg, cube, dev):
+    return [(torch.linspace(-s / 2, s / 2, n) + c).contiguous().to(dev)
+            for s, n, c in zip(cfg['space_size'], cube, cfg['space_center'])]
+
+
+@pytest.mark.parametrize('joints,extra', [(15, 0), (17, 0), (15, 17), (32, 0)])
+def test_channels_last_maps_read_in_place(joints, extra, gpu_device):
+    """V channels_last tensors read in place (texel = 4*C_total bytes: 60 B at 15 joints,
+    not a multiple of the 16-byte fetch) vs the repacked path: bit-identical for the fused
+    root and window kernels; small maps so that the corner texels
+    are sampled.  `extra` leading channels exercise the channel-slice offset."""
+    import tempo_amd
+    from tempo_amd import ops, synthetic as S
+    from tempo_amd.camera import pack_cameras
+    dev = gpu_device
+    cfg = dict(S.PANOPTIC, heatmap_size=[24, 14], num_joints=joints)
+    V, B, cube = 5, 3, [12, 12, 6]
+    cams = S.ring_cameras(V, seed=71, target=cfg['space_center'])
+    centers, scales, cameras = S.frame_meta(cams, B, cfg['raw_size'], cfg['image_size'])
+    cam_host = pack_cameras(centers, scales, cameras, cfg['image_size'])
+    cam = cam_host.to(dev)
+    C_total = joints + extra
+    g = torch.Generator().manual_seed(72)
+    nchw = [torch.rand(B, C_total, 14, 24, generator=g).to(dev) for _ in range(V)]
+    nhwc = [f.contiguous(memory_format=torch.channels_last) for f in nchw]
+    assert all(ops.is_channels_last(f) for f in nhwc)
+    axes = _axes(cfg, cube, dev)
+    hm = ops.repack_nhwc(nchw, extra, joints)
+    ref = ops.unproject_root(hm, cam, axes, joints, cfg['heatmap_size'], cfg['image_size'],
+                             want_grids=True, want_mask=True)
+    lay = ops.channels_last_layout(nhwc, extra)
+    got = ops.unproject_root_views(lay, cam, axes, joints, cfg['heatmap_size'],
+                                   cfg['image_size'], want_grids=True, want_mask=True)
+    torch.cuda.synchronize()
+    for a, b, what in zip(got, ref, ('cubes', 'grids', 'mask')):
+        assert torch.equal(_canon(a), _canon(b)), what
+    assert float(ref[0].max()) > 0.0
+    # windows
+    space, sub, sub_cube = [2400, 2400, 1800], [1200, 1200, 900], [12, 12, 12]
+    layer = tempo_amd.ProjectLayerWithMask(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    layer.set_space_size(cfg['space_center'], space, sub, sub_cube, dev)
+    props = S.make_proposals(B, cfg['space_center'], space, seed=73, invalid_every=0, margin=0.0)
+    tl, _, st, en = layer.window_geometry(props.to(dev))
+    layer._ensure_grids(dev)
+    geo = [t.to(torch.int32).contiguous() for t in (tl, st, en)]
+    wref = ops.unproject_window(hm, cam, layer._fine_axes, *geo, sub_cube, joints,
+                                cfg['heatmap_size'], cfg['image_size'])
+    wgot = ops.unproject_window_views(lay, cam, layer._fine_axes, *geo, sub_cube, joints,
+                                      cfg['heatmap_size'], cfg['image_size'])
+    torch.cuda.synchronize()
+    assert torch.equal(_canon(wgot), _canon(wref))
+    assert float(wref.max()) > 0.0
+
+
+def test_gather_zcolumns_equals_the_detectors_torch_gather(gpu_device):
+    """tempo_detector.py:204-206, restated with torch ops, vs the kernel (bit-equal)."""
+    from tempo_amd import ops
+    dev = gpu_device
+    g = torch.Generator().manual_seed(3)
+    for (B, C, X, Y, Z, K) in ((4, 15, 80, 80, 20, 10), (2, 32, 7, 5, 9, 3), (1, 1, 2, 2, 1, 4)):
+        cubes = torch.rand(B, C, X, Y, Z, generator=g).to(dev)
+        index = torch.randint(0, X * Y, (B, K), generator=g).to(dev)
+        ref = torch.gather(torch.flatten(cubes, 2, 3).permute(0, 2, 1, 3), dim=1,
+                           index=index.view(B, -1, 1, 1).repeat(1, 1, C, Z))
+        got = ops.gather_zcolumns(cubes, index)
+        assert got.shape == ref.shape and torch.equal(got, ref)
+    bad = torch.tensor([[0, X * Y, -1, 1]], device=dev)
+    got = ops.gather_zcolumns(cubes, bad)
+    assert float(got[0, 1].abs().max()) == 0.0 and float(got[0, 2].abs().max()) == 0.0
+    assert torch.equal(got[0, 0], cubes[0, :, 0, 0, :]) and torch.equal(got[0, 3], cubes[0, :, 0, 1, :])
