@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define TEMPO_ABI_VERSION 6
+#define TEMPO_ABI_VERSION 7
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
@@ -349,6 +349,24 @@ int tempo_unproject_window_backward(const float* grad_cubes, const float* cam,
 int tempo_unrepack_nchw(const float* in, void* const* views, int V, int B,
                         int C_total, int c_begin, int C, int H, int W, int CP,
                         void* stream);
+
+/* The 2-D head's 1x1 convolution with the unprojection's input layout as its output:
+ * rnn_multiview_pose.py:61-66 (process_layer = nn.Conv2d(256, num_features, 1)) applied
+ * at :321 to the backbone map of all T*V*B images, then chunked into
+ * feature_maps[t][v] = [B, C, H, W] at :324-326.  Writing channel-last directly removes
+ * the NCHW tensor and the repack (tempo_repack_nhwc) that would read it back.
+ *   in     : fp32 [T*V*B, K, H, W], images ordered (t, v, b) as torch.cat builds them
+ *   weight : fp32 [C, K] (the conv's weight[:, :, 0, 0]);  bias : fp32 [C] or NULL
+ *   out    : fp32 [T*B, V, H, W, CP], frame = t * B + b; channels C..CP-1 are zero;
+ *            16-byte aligned.  The result of frames [t*B, (t+1)*B) is the `hm` argument of
+ *            tempo_unproject_root / _window for timestep t.
+ * fp32 MFMA (v_mfma_f32_16x16x4_f32): each output is an fp32 FMA chain over k ascending,
+ * then + bias -- the same precision class as F.conv2d in fp32, not bit-identical to it
+ * (libraries sum in their own order).  K * 16 * ceil(CP / 16) * 4 bytes of weights must
+ * fit 64 KB of LDS (K <= 1024 at CP = 16, 512 at CP = 32: TEMPO_E_DIM beyond). */
+int tempo_conv1x1_nhwc(const float* in, const float* weight, const float* bias, float* out,
+                       int T, int V, int B, int K, int C, int CP, int H, int W,
+                       void* stream);
 
 /* z-columns of the root volume at K (x, y) cells per frame -- what the detector's 1-D
  * stage reads (tempo_detector.py:204-206: torch.gather(torch.flatten(cubes, 2, 3)

@@ -1637,6 +1637,122 @@ void launch_unrepack_wide(const UnrepackArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL((unrepack_wide_kernel<L>), grid, dim3(kThreads), 0, stream, a);
 }
 
+// ------------------------------------------- 1x1 convolution, channel-last out
+// The 2-D head's last layer in front of the unprojection is a 1x1 convolution
+// (rnn_multiview_pose.py:61-66, :321: process_layer = nn.Conv2d(256, num_features, 1) on the
+// backbone map of all T*V*B images, then chunked into feature_maps[t][v]).  This kernel is
+// that layer with the unprojection's own input layout as its output: out[frame][view][pixel]
+// [CP channels], frames ordered (t, b), so no NCHW tensor is written and no repack reads it
+// back.  A [pixels x K] x [K x channels] contraction per image: f32-input MFMA
+// (v_mfma_f32_16x16x4_f32: exact fp32 FMA chains), A = weights (channels x k), B = input
+// (k x pixels).  One wave owns 64 consecutive pixels of one image; per k-step of 4 planes a
+// lane loads 4 consecutive pixels of plane k0 + lane / 16 (16 lanes = 256 contiguous bytes
+// per plane), which are the B operands of four MFMAs whose column j stands for pixel
+// 4 j + t.  The accumulators then hold, per lane, 4 consecutive channels of one pixel: one
+// 16-byte store each, 64 contiguous bytes (CP = 16) per pixel.  HBM-bound: the input is
+// K * 4 bytes per pixel, read once.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const float* in;      // [T*V*B][K][HW]
+  const float* weight;  // [C][K]
+  const float* bias;    // [C] or nullptr
+  float* out;           // [T*B][V][HW][CP]
+  int V, B, K, C, CP, HW;
+  int images;           // T * V * B, ordered (t, v, b)
+  int tiles;            // 64-pixel tiles per image
+  int vec;              // HW % 4 == 0 and 16-byte aligned input: 128-bit loads
+};
+
+#ifndef TEMPO_CONV_STEP
+#define TEMPO_CONV_STEP 8
+#endif
+constexpr int kConvStep = TEMPO_CONV_STEP;  // k-steps (of 4 planes) whose loads are in flight together
+
+template <int NT>  // channel tiles of 16: CP = 16 NT
+__global__ __launch_bounds__(kThreads) void conv1x1_nhwc_kernel(const ConvArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* wl = reinterpret_cast<float*>(smem);  // [K][16 NT], zero rows for channels >= C
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < a.K * 16 * NT; i += kThreads) {
+    const int k = i / (16 * NT), c = i - k * (16 * NT);
+    wl[i] = c < a.C ? a.weight[(long long)c * a.K + k] : 0.0f;
+  }
+  __syncthreads();
+  const long long item = (long long)blockIdx.x * (kThreads / 64) + wave;
+  const int img = (int)(item / a.tiles);
+  if (img >= a.images) return;
+  const int p0 = (int)(item - (long long)img * a.tiles) * 64;
+  // image m = (t * V + v) * B + b  ->  frame t * B + b, view v
+  const int t_ = img / (a.V * a.B), v_ = (img / a.B) % a.V, b_ = img % a.B;
+  const float* src = a.in + (long long)img * a.K * a.HW;
+  const int kq = lane >> 4, jj = lane & 15;
+  const int px = p0 + 4 * jj;  // this lane's four pixels: px .. px + 3
+
+  auto load = [&](int k0) -> f32x4 {
+    const float* q = src + (long long)(k0 + kq) * a.HW + px;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+    if (k0 + kq < a.K) {
+      if (a.vec) {
+        if (px < a.HW) x = *reinterpret_cast<const f32x4*>(q);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (px + e < a.HW) x[e] = q[e];
+      }
+    }
+    return x;
+  };
+
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int n = 0; n < NT; n++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) acc[n][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  f32x4 cur[kConvStep], nxt[kConvStep];
+#pragma unroll
+  for (int u = 0; u < kConvStep; u++) cur[u] = load(4 * u);
+#pragma unroll 1
+  for (int k0 = 0; k0 < a.K; k0 += 4 * kConvStep) {
+#pragma unroll
+    for (int u = 0; u < kConvStep; u++) nxt[u] = load(k0 + 4 * (kConvStep + u));
+#pragma unroll
+    for (int u = 0; u < kConvStep; u++) {
+      const int k = k0 + 4 * u + kq;
+#pragma unroll
+      for (int n = 0; n < NT; n++) {
+        const float w = k < a.K ? wl[k * (16 * NT) + 16 * n + jj] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          acc[n][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(w, cur[u][e], acc[n][e], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kConvStep; u++) cur[u] = nxt[u];
+  }
+
+  // lane: channels 16 n + 4 kq .. + 3 of pixel px + e
+  float* dst = a.out + (((long long)(t_ * a.B + b_) * a.V + v_) * a.HW) * a.CP;
+#pragma unroll
+  for (int n = 0; n < NT; n++) {
+    const int c0 = 16 * n + 4 * kq;
+    if (c0 >= a.CP) continue;
+    f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr) {
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        if (c0 + r < a.C) bs[r] = a.bias[c0 + r];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      if (px + e < a.HW)
+        *reinterpret_cast<f32x4*>(dst + (long long)(px + e) * a.CP + c0) = acc[n][e] + bs;
+    }
+  }
+}
+
 // ------------------------------------------------------------ z-column gather
 // The root detector's second stage reads, for each of its K best (x, y) cells, the
 // z-column of every channel (tempo_detector.py:204-206: torch.gather on the flattened,
@@ -2451,6 +2567,36 @@ int window_impl(const Layout& lay, const float* cam, const int32_t* win_frame, c
 }  // namespace
 
 extern "C" {
+
+int tempo_conv1x1_nhwc(const float* in, const float* weight, const float* bias, float* out,
+                       int T, int V, int B, int K, int C, int CP, int H, int W, void* stream) {
+  if (!in || !weight || !out) return TEMPO_E_NULL;
+  if (T <= 0 || V <= 0 || V > TEMPO_MAX_VIEWS || B <= 0 || K <= 0 || C <= 0 ||
+      C > TEMPO_MAX_CHANNELS || H <= 0 || W <= 0 || (long long)T * V * B > 0x7fffffffLL)
+    return TEMPO_E_DIM;
+  if (CP % 4 != 0 || CP < C || CP < 16 || CP > TEMPO_MAX_CHANNELS) return TEMPO_E_PAD;
+  if (!aligned16(out)) return TEMPO_E_ARG;
+  const long long HW = (long long)H * W;
+  if (HW * CP * 4 >= 0x80000000LL || HW * K >= 0x7fffffffLL) return TEMPO_E_SIZE;
+  const int nt = (CP + 15) / 16;
+  if ((size_t)K * 16 * nt * 4 > 65536) return TEMPO_E_DIM;  // the weights live in LDS
+  ConvArgs a = {};
+  a.in = in; a.weight = weight; a.bias = bias; a.out = out;
+  a.V = V; a.B = B; a.K = K; a.C = C; a.CP = CP; a.HW = (int)HW;
+  a.images = T * V * B;
+  a.tiles = (int)((HW + 63) / 64);
+  a.vec = (HW % 4 == 0) && aligned16(in);
+  const long long waves = (long long)T * V * B * a.tiles;
+  const long long blocks = (waves + kThreads / 64 - 1) / (kThreads / 64);
+  if (blocks > 0x7fffffffLL) return TEMPO_E_DIM;
+  const size_t lds = (size_t)K * 16 * nt * 4;
+  const dim3 grid((unsigned)blocks);
+  if (nt == 1)
+    hipLaunchKernelGGL((conv1x1_nhwc_kernel<1>), grid, dim3(kThreads), lds, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((conv1x1_nhwc_kernel<2>), grid, dim3(kThreads), lds, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
 
 int tempo_gather_zcolumns(const float* cubes, const int64_t* index, float* out, int B, int K,
                           int C, int X, int Y, int Z, void* stream) {

@@ -765,3 +765,42 @@ def gather_zcolumns(cubes, index, out=None):
                                        _stream_ptr(dev))
     _lib.check(rc, 'tempo_gather_zcolumns')
     return out
+
+
+def conv1x1_nhwc(x, weight, bias, num_views, timesteps=1, out=None):
+    """The 2-D head's 1x1 convolution (``rnn_multiview_pose.py:61-66, :321``) writing the
+    unprojection's channel-last layout directly.
+
+    ``x`` fp32 ``[T*V*B, K, H, W]`` (images ordered (t, v, b), as the reference stacks them),
+    ``weight`` ``[C, K]`` or ``[C, K, 1, 1]``, ``bias`` ``[C]`` or None.  Returns
+    ``[T*B, V, H, W, CP]``: ``out[t*B:(t+1)*B]`` is the repacked ``hm`` of timestep t (what
+    :func:`repack_nhwc` would produce from ``feature_maps[t]``)."""
+    lib = _lib.load()
+    dev = x.device
+    _need(x, torch.float32, 'x')
+    M, K, H, W = (int(v) for v in x.shape)
+    V, T = int(num_views), int(timesteps)
+    if M % (V * T):
+        raise ValueError('x.shape[0] must be timesteps * num_views * batch')
+    B = M // (V * T)
+    w2 = weight.reshape(weight.shape[0], -1)
+    _need(w2, torch.float32, 'weight', dev)
+    C = int(w2.shape[0])
+    if int(w2.shape[1]) != K:
+        raise ValueError(f'weight must be [C,{K}]')
+    if bias is not None:
+        _need(bias, torch.float32, 'bias', dev)
+        if bias.numel() != C:
+            raise ValueError('bias must have C entries')
+    CP = padded_channels(C)
+    if out is None:
+        out = torch.empty(T * B, V, H, W, CP, dtype=torch.float32, device=dev)
+    else:
+        _need(out, torch.float32, 'out', dev)
+        if out.numel() != T * B * V * H * W * CP:
+            raise ValueError('out has the wrong size')
+    with torch.cuda.device(dev):
+        rc = lib.tempo_conv1x1_nhwc(_ptr(x), _ptr(w2), _ptr(bias), _ptr(out), T, V, B, K, C, CP,
+                                    H, W, _stream_ptr(dev))
+    _lib.check(rc, 'tempo_conv1x1_nhwc')
+    return out

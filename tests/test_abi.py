@@ -12,7 +12,7 @@ HEADER = os.path.join(ROOT, 'include', 'tempo_unproject.h')
 
 def _declared():
     text = re.sub(r'/\*.*?\*/', '', open(HEADER).read(), flags=re.S)
-    return sorted(set(re.findall(r'\b(tempo_[a-z_]+)\s*\(', text)))
+    return sorted(set(re.findall(r'\b(tempo_[a-z0-9_]+)\s*\(', text)))
 
 
 def test_header_and_binding_agree():

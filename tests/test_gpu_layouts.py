@@ -81,3 +81,38 @@ def test_gather_zcolumns_equals_the_detectors_torch_gather(gpu_device):
     got = ops.gather_zcolumns(cubes, bad)
     assert float(got[0, 1].abs().max()) == 0.0 and float(got[0, 2].abs().max()) == 0.0
     assert torch.equal(got[0, 0], cubes[0, :, 0, 0, :]) and torch.equal(got[0, 3], cubes[0, :, 0, 1, :])
+
+
+@pytest.mark.parametrize('T,V,B,K,C,H,W', [(1, 2, 2, 256, 15, 16, 24), (2, 3, 1, 64, 32, 9, 13),
+                                           (1, 1, 2, 100, 17, 8, 8), (1, 5, 1, 256, 15, 128, 240)])
+def test_conv1x1_nhwc_producer(T, V, B, K, C, H, W, gpu_device):
+    """process_layer (rnn_multiview_pose.py:61-66, :321) with channel-last output: against
+    F.conv2d evaluated in float64 (bar: 2e-6 * sum|w||x|-scale, i.e. fp32 FMA-chain
+    rounding; torch's own fp32 conv is held to the same bar), layout = what repack_nhwc
+    produces from the chunked NCHW result, padding channels zero."""
+    import torch.nn.functional as F
+    from tempo_amd import ops
+    dev = gpu_device
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(T * V * B, K, H, W, generator=g).to(dev)
+    w = (torch.randn(C, K, 1, 1, generator=g) / K ** 0.5).to(dev)
+    bias = torch.randn(C, generator=g).to(dev)
+    got = ops.conv1x1_nhwc(x, w, bias, num_views=V, timesteps=T)
+    cp = ops.padded_channels(C)
+    assert got.shape == (T * B, V, H, W, cp)
+    ref64 = F.conv2d(x.double(), w.double(), bias.double())
+    ref32 = F.conv2d(x, w, bias)
+    # feature_maps[t][v] = chunk(chunk(map, T)[t], V)[v]  ->  [T*B, V, H, W, C]
+    def regroup(m):
+        return m.view(T, V, B, C, H, W).permute(0, 2, 1, 4, 5, 3).reshape(T * B, V, H, W, C)
+    scale = float((w.double().abs().view(1, C, K, 1, 1) * x.double().abs().unsqueeze(1)).sum(2).max())
+    err = float((got[..., :C].double() - regroup(ref64)).abs().max())
+    err32 = float((regroup(ref32).double() - regroup(ref64)).abs().max())
+    print(f'\n[conv1x1 K={K} C={C}] max-abs vs fp64: ours {err:.3e}, torch fp32 {err32:.3e}, scale {scale:.2f}')
+    assert err <= 2e-6 * scale
+    assert float(got[..., C:].abs().max()) == 0.0 if cp > C else True
+    # the same tensor the repack produces from the NCHW feature maps (values to rounding)
+    fms = [regroup(ref32)[:B, v].permute(0, 3, 1, 2).contiguous() for v in range(V)]
+    hm = ops.repack_nhwc(fms)
+    assert hm.shape == got[:B].shape
+    assert float((hm - got[:B]).abs().max()) <= 4e-6 * scale
