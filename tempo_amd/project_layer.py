@@ -33,8 +33,71 @@ def _triple(v, kinds):
     return [v, v, v] if isinstance(v, kinds) else v
 
 
+class PackedHeatmaps:
+    """The V per-view feature maps of one timestep, already in the kernels' channel-last
+    layout: ``hm [B,V,H,W,CP]`` with ``channels`` real channels (what
+    :class:`ProcessLayerNHWC` / ``tempo_conv1x1_nhwc`` writes).  Pass it to the project
+    layers where the reference passes ``feature_maps[t]``: the repack is skipped.  For
+    other consumers it still behaves like the reference's list: ``len()`` = V and ``[v]``
+    is a ``[B,C,H,W]`` view (strided, no copy)."""
+
+    def __init__(self, hm, channels):
+        if hm.dim() != 5 or hm.dtype != torch.float32 or not hm.is_contiguous():
+            raise ValueError('PackedHeatmaps needs a contiguous fp32 [B,V,H,W,CP] tensor')
+        if not 0 < channels <= hm.shape[-1] or hm.shape[-1] != ops.padded_channels(channels):
+            raise ValueError('the last dimension must be padded_channels(channels)')
+        self.hm = hm
+        self.channels = int(channels)
+
+    def __len__(self):
+        return int(self.hm.shape[1])
+
+    def __getitem__(self, v):
+        return self.hm[:, v, :, :, :self.channels].permute(0, 3, 1, 2)
+
+    def __iter__(self):
+        return (self[v] for v in range(len(self)))
+
+
+class ProcessLayerNHWC(nn.Module):
+    """The reference's ``process_layer = nn.Conv2d(256, num_features, 1)``
+    (``rnn_multiview_pose.py:61-66``) with the unprojection's layout as its output: same
+    parameters (``weight [C,K,1,1]``, ``bias [C]``: state dicts are interchangeable),
+    ``forward`` returns what ``:324-326`` builds -- one entry per timestep -- as
+    :class:`PackedHeatmaps` instead of lists of NCHW tensors.  Inference only: a training
+    step goes through ``F.conv2d`` (autograd) and returns the reference's lists."""
+
+    def __init__(self, in_channels=256, out_channels=32):
+        super().__init__()
+        conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)  # the reference's init
+        self.weight, self.bias = conv.weight, conv.bias
+
+    def forward(self, backbone_map, num_views, timesteps=1):
+        if torch.is_grad_enabled() and (backbone_map.requires_grad or self.weight.requires_grad):
+            out = torch.nn.functional.conv2d(backbone_map, self.weight, self.bias)
+            return [list(torch.chunk(m, num_views)) for m in torch.chunk(out, timesteps)]
+        hm = ops.conv1x1_nhwc(backbone_map.float().contiguous(), self.weight.detach(),
+                              self.bias.detach(), num_views, timesteps)
+        B = hm.shape[0] // timesteps
+        C = int(self.weight.shape[0])
+        return [PackedHeatmaps(hm[t * B:(t + 1) * B], C) for t in range(timesteps)]
+
+
+def _map_source(feature_maps):
+    """How the forward kernels get at the maps: ('packed', PackedHeatmaps),
+    ('views', list of channels_last tensors read in place) or ('nchw', list to repack)."""
+    if isinstance(feature_maps, PackedHeatmaps):
+        return 'packed'
+    if all(ops.is_channels_last(fm) and fm.is_cuda for fm in feature_maps):
+        return 'views'
+    return 'nchw'
+
+
 def _check_inputs(feature_maps):
-    fm0 = feature_maps[0]
+    if isinstance(feature_maps, PackedHeatmaps):
+        fm0 = feature_maps.hm
+    else:
+        fm0 = feature_maps[0]
     if not fm0.is_cuda:
         raise RuntimeError('tempo_amd.ProjectLayer runs on HIP devices only; got a '
                            f'{fm0.device} tensor (there is no CPU fallback)')
@@ -42,7 +105,15 @@ def _check_inputs(feature_maps):
 
 
 def _wants_grad(feature_maps):
+    if isinstance(feature_maps, PackedHeatmaps):
+        return False
     return torch.is_grad_enabled() and any(fm.requires_grad for fm in feature_maps)
+
+
+def _batch_channels(feature_maps):
+    if isinstance(feature_maps, PackedHeatmaps):
+        return int(feature_maps.hm.shape[0]), feature_maps.channels
+    return int(feature_maps[0].shape[0]), int(feature_maps[0].shape[1])
 
 
 class _Unproject(torch.autograd.Function):
@@ -217,7 +288,7 @@ class ProjectLayer(nn.Module):
         """``zslab=(z0, z1)`` (extension, used by ``tempo_amd.parallel``): compute
         only planes ``[z0, z1)`` of the grid; returns ``[B,C,X,Y,z1-z0]``."""
         device = _check_inputs(feature_maps)
-        B, C = feature_maps[0].shape[:2]
+        B, C = _batch_channels(feature_maps)
         live = self._live(grid_center, B, device)
         axes, cube_size = self._axes(grid_size, grid_center, cube_size, B, device)
         if zslab is not None:
@@ -242,6 +313,12 @@ class ProjectLayer(nn.Module):
             return cubes, meta.get('grids')
         cubes = torch.empty(B, C, *cube_size, dtype=torch.float32, device=device)
         grids = mask = None
+        source = _map_source(feature_maps)
+        if source == 'packed' or (source == 'views' and not self.keep_zmax):
+            # maps already channel-last: read in place, no repack (frames in chunks of 8:
+            # one frame per XCD at a time)
+            self.last_zmax = None
+            return self._get_voxel_in_place(feature_maps, source, cam, axes, live, cubes)
         zmax = (torch.empty(B, C, cube_size[0], cube_size[1], dtype=torch.float32,
                             device=device) if self.keep_zmax and groups is None else None)
         for c0, cs in _Slices(C).items:
@@ -267,6 +344,45 @@ class ProjectLayer(nn.Module):
                 cubes[:, c0:c0 + cs] = out
             if first:
                 grids, mask = g, m
+        self.last_mask = mask
+        self.last_zmax = zmax
+        return cubes, grids
+
+    def _get_voxel_in_place(self, feature_maps, source, cam, axes, live, cubes):
+        B, C = cubes.shape[:2]
+        batched = axes[0].dim() == 2
+        grids = mask = None
+        zmax = None
+        if source == 'packed' and self.keep_zmax:
+            zmax = torch.empty(B, C, cubes.shape[2], cubes.shape[3], dtype=torch.float32,
+                               device=cubes.device)
+        chunk = ops.ROOT_CHUNK_FRAMES
+        for c0, cs in _Slices(C).items:
+            first = c0 == 0
+            out = cubes if cs == C else torch.empty(B, cs, *cubes.shape[2:], dtype=torch.float32,
+                                                    device=cubes.device)
+            gl, ml = [], []
+            for b0 in range(0, B, chunk):
+                sl = slice(b0, min(B, b0 + chunk))
+                ax = [a[sl] for a in axes] if batched else axes
+                lv = None if live is None else live[sl]
+                kw = dict(live=lv, want_grids=first and self.materialize_grids,
+                          want_mask=first and self.keep_mask, out=out[sl], mm_mode=self.mm_mode)
+                if source == 'packed':  # (at most 32 channels: one slice)
+                    _, g, m = ops.unproject_root(
+                        feature_maps.hm[sl], cam[sl], ax, cs, self.heatmap_size, self.image_size,
+                        zmax_out=None if zmax is None else zmax[sl], **kw)
+                else:
+                    lay = ops.channels_last_layout([fm[sl] for fm in feature_maps], c0)
+                    _, g, m = ops.unproject_root_views(lay, cam[sl], ax, cs, self.heatmap_size,
+                                                       self.image_size, **kw)
+                gl.append(g)
+                ml.append(m)
+            if cs != C:
+                cubes[:, c0:c0 + cs] = out
+            if first:
+                grids = torch.cat(gl, 0) if gl[0] is not None else None
+                mask = torch.cat(ml, 0) if ml[0] is not None else None
         self.last_mask = mask
         self.last_zmax = zmax
         return cubes, grids
@@ -414,7 +530,7 @@ class ProjectLayerWithMask(nn.Module):
         """Per-call constants of the window kernels: integer window geometry
         (``project_layer.py:299-324``), skip flags (``:232``), packed cameras."""
         device = _check_inputs(feature_maps)
-        B, C = feature_maps[0].shape[:2]
+        B, C = _batch_channels(feature_maps)
         if grid_center.device != device:
             grid_center = grid_center.to(device)
         centers_tl, offset, start, end = self.window_geometry(grid_center)
@@ -438,6 +554,22 @@ class ProjectLayerWithMask(nn.Module):
             cubes = _Unproject.apply(meta, *[fm.float() for fm in feature_maps])
             return cubes, offset
         cubes = torch.empty(B, C, *self._sub_cube, dtype=torch.float32, device=device)
+        source = _map_source(feature_maps)
+        if source == 'packed':  # already channel-last: no repack
+            ops.unproject_window(feature_maps.hm, cam, self._fine_axes, tl, st, en,
+                                 self._sub_cube, C, self.heatmap_size, self.image_size,
+                                 live=live, out=cubes, mm_mode=self.mm_mode)
+            return cubes, offset
+        if source == 'views':  # channels_last tensors read in place
+            for c0, cs in _Slices(C).items:
+                lay = ops.channels_last_layout(list(feature_maps), c0)
+                out = ops.unproject_window_views(
+                    lay, cam, self._fine_axes, tl, st, en, self._sub_cube, cs,
+                    self.heatmap_size, self.image_size, live=live,
+                    out=cubes if cs == C else None, mm_mode=self.mm_mode)
+                if cs != C:
+                    cubes[:, c0:c0 + cs] = out
+            return cubes, offset
         for c0, cs in _Slices(C).items:
             out, _ = ops.window_step(
                 feature_maps, cam, self._fine_axes, tl, st, en, self._sub_cube,

@@ -116,3 +116,109 @@ def test_conv1x1_nhwc_producer(T, V, B, K, C, H, W, gpu_device):
     hm = ops.repack_nhwc(fms)
     assert hm.shape == got[:B].shape
     assert float((hm - got[:B]).abs().max()) <= 4e-6 * scale
+
+
+def test_modules_take_channels_last_and_packed_maps(gpu_device):
+    """The drop-in modules with (i) NCHW lists (repack), (ii) channels_last lists (read in
+    place), (iii) PackedHeatmaps: bit-identical to each other, and <= 1e-5 / mask bit-exact
+    against the oracle; root (mask, grids, z-max) and window."""
+    import cases
+    import tempo_amd
+    from oracle import project_layer_ref as O
+    dev = gpu_device
+    case = cases.build_root('root_panoptic_noise')
+    dcase = cases.to_device(case, dev)
+    fms = dcase['args'][0]
+    rest = dcase['args'][1:]
+    ref_layer = O.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    ref, ref_grids = ref_layer(*case['args'])
+    from tempo_amd import ops
+    variants = {
+        'nchw': fms,
+        'channels_last': [f.contiguous(memory_format=torch.channels_last) for f in fms],
+        'packed': tempo_amd.PackedHeatmaps(ops.repack_nhwc(fms), fms[0].shape[1]),
+    }
+    outs = {}
+    for name, maps in variants.items():
+        layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+        layer.keep_mask = True
+        layer.keep_zmax = name != 'channels_last'
+        with torch.no_grad():
+            cubes, grids = layer(maps, *rest)
+        outs[name] = (cubes, grids, layer.last_mask)
+        if layer.keep_zmax:
+            assert torch.equal(_canon(layer.last_zmax), _canon(cubes.max(dim=4)[0]))
+    for name in ('channels_last', 'packed'):
+        for a, b in zip(outs[name], outs['nchw']):
+            assert torch.equal(_canon(a), _canon(b)), name
+    assert float((_canon(outs['packed'][0].cpu()) - _canon(ref)).abs().max()) <= 1e-5
+    assert torch.equal(outs['packed'][1].cpu(), ref_grids)
+    V = ref_layer.last_bounding.shape[-1]
+    bits = (ref_layer.last_bounding.to(torch.int32) << torch.arange(V, dtype=torch.int32)).sum(-1)
+    assert torch.equal(outs['packed'][2].cpu().to(torch.int32), bits)
+    # PackedHeatmaps still reads like the reference's list of [B,C,H,W] tensors
+    pk = variants['packed']
+    assert len(pk) == len(fms) and all(torch.equal(pk[v], fms[v]) for v in range(len(fms)))
+
+    case = cases.build_window('win_h36m_noise')  # 17 joints: 68-byte texels in place
+    dcase = cases.to_device(case, dev)
+    fms = dcase['args'][0]
+    rest = dcase['args'][1:]
+    ref, ref_off = O.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')(
+        *case['args'])
+    variants = {
+        'nchw': fms,
+        'channels_last': [f.contiguous(memory_format=torch.channels_last) for f in fms],
+        'packed': tempo_amd.PackedHeatmaps(ops.repack_nhwc(fms), fms[0].shape[1]),
+    }
+    outs = {}
+    for name, maps in variants.items():
+        layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+        with torch.no_grad():
+            outs[name] = layer(maps, *rest)
+    for name in ('channels_last', 'packed'):
+        assert torch.equal(outs[name][0], outs['nchw'][0]) and torch.equal(outs[name][1], outs['nchw'][1])
+    assert float((outs['packed'][0].cpu() - ref).abs().max()) <= 1e-5
+    assert torch.equal(outs['packed'][1].cpu(), ref_off)
+
+
+def test_process_layer_nhwc_feeds_the_project_layer(gpu_device):
+    """rnn_multiview_pose.py:321-326 + tempo_detector.py:187: backbone map -> process_layer
+    -> feature_maps[t] -> ProjectLayer, with ProcessLayerNHWC + PackedHeatmaps against
+    nn.Conv2d + the oracle (the conv's rounding differs from torch's by ~1e-6, so the volume
+    is held to 2e-5 here; the unprojection itself is exact, see the other tests)."""
+    import tempo_amd
+    from oracle import project_layer_ref as O
+    from tempo_amd import synthetic as S
+    dev = gpu_device
+    cfg = dict(S.PANOPTIC, heatmap_size=[60, 32])
+    T, V, B, K, C = 2, 5, 2, 64, 15
+    torch.manual_seed(21)
+    layer2d = tempo_amd.ProcessLayerNHWC(K, C).to(dev)
+    ref2d = torch.nn.Conv2d(K, C, 1)
+    ref2d.load_state_dict({k: v.cpu() for k, v in layer2d.state_dict().items()})
+    x = torch.rand(T * V * B, K, 32, 60) * 0.2
+    cams = S.ring_cameras(V, seed=22, target=cfg['space_center'])
+    centers, scales, cameras = S.frame_meta(cams, B, cfg['raw_size'], cfg['image_size'])
+    cube = [14, 12, 8]
+    with torch.no_grad():
+        ref_map = ref2d(x)
+        ref_fms = [list(torch.chunk(m, V)) for m in torch.chunk(ref_map, T)]
+        got_fms = layer2d(x.to(dev), num_views=V, timesteps=T)
+    assert len(got_fms) == T and isinstance(got_fms[0], tempo_amd.PackedHeatmaps)
+    proj = tempo_amd.ProjectLayer(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    oracle = O.ProjectLayer(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    for t in range(T):
+        for v in range(V):
+            assert float((got_fms[t][v].cpu() - ref_fms[t][v]).abs().max()) <= 1e-5
+        with torch.no_grad():
+            cubes, _ = proj(got_fms[t], cfg['space_size'], [cfg['space_center']], cube, centers,
+                            scales, cameras)
+        ref, _ = oracle(ref_fms[t], cfg['space_size'], [cfg['space_center']], cube, centers,
+                        scales, cameras)
+        assert float(ref.max()) > 0.0
+        assert float((_canon(cubes.cpu()) - _canon(ref)).abs().max()) <= 2e-5
+    # training mode: autograd through F.conv2d, the reference's list format
+    xg = x.to(dev).requires_grad_(True)
+    lists = layer2d(xg, num_views=V, timesteps=T)
+    assert isinstance(lists[0], list) and lists[0][0].shape == (B, C, 32, 60)
