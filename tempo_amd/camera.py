@@ -198,6 +198,60 @@ def _record_for(param, mm_mode):
     return rec
 
 
+# Whole packed tables per CALL SHAPE, across calls: the callers hand over the same per-frame
+# list objects again and again -- the pose regressor once per candidate and timestep
+# (tempo_pose.py:145-156, :266), the detector once per timestep -- and building the content
+# keys of 160 dicts costs ~1 ms of host time.  Key = identities of the per-frame lists;
+# an entry keeps those lists alive (so an id cannot be reused) and a fingerprint of every
+# dict (identity of the dict and of its R / T / K values, two sampled numbers), so that a
+# replaced or rebuilt dict is seen.  Calibration VALUES mutated in place inside an array that
+# was passed before are not re-read: treat passed calibrations as constants, or call
+# ``clear_cache()``.
+_TABLES = {}
+_TABLES_MAX = 64
+
+
+_ON_DEVICE = {}  # (id(host table), device) -> (host table, device copy)
+
+
+def clear_cache():
+    _TABLES.clear()
+    _RECORDS.clear()
+    _ON_DEVICE.clear()
+
+
+def to_device(table, device):
+    """Device copy of a packed table; tables that :func:`pack_cameras` returned from its
+    cache (same object as last time) are copied once per device."""
+    if table.device == torch.device(device):
+        return table
+    key = (id(table), str(device))
+    hit = _ON_DEVICE.get(key)
+    if hit is not None and hit[0] is table:
+        return hit[1]
+    dev = table.to(device)
+    if len(_ON_DEVICE) >= _TABLES_MAX:
+        _ON_DEVICE.clear()
+    _ON_DEVICE[key] = (table, dev)
+    return dev
+
+
+def _num(x):
+    while not isinstance(x, (int, float)):
+        x = x[0]
+    return float(x)
+
+
+def _fingerprint(centers, scales, cameras):
+    fp = []
+    for cb, sb, mb in zip(centers, scales, cameras):
+        for c, sc, m in zip(cb, sb, mb):
+            r, t = m.get('R'), m.get('T')
+            fp.append((id(m), id(r), id(t), id(m.get('K', m.get('f'))), len(m),
+                       _num(r), _num(t), float(c[0]), float(c[1]), float(sc[0])))
+    return fp
+
+
 def pack_cameras(centers, scales, cameras, image_size, mm_mode='auto'):
     """``centers[b][v]``, ``scales[b][v]`` (np.float32 (2,)), ``cameras[b][v]``
     (dict) -> CPU fp32 tensor ``[B,V,32]``.  ``mm_mode``: rounding flavour used
@@ -215,6 +269,27 @@ def pack_cameras(centers, scales, cameras, image_size, mm_mode='auto'):
     for b in range(B):
         if len(cameras[b]) != V or len(centers[b]) != V or len(scales[b]) != V:
             raise ValueError('every batch item needs one center/scale/camera per view')
+    mode = mm_mode if isinstance(mm_mode, (str, type(None))) else tuple(sorted(mm_mode.items()))
+    try:
+        call_key = (tuple(map(id, cameras)), tuple(map(id, centers)), tuple(map(id, scales)),
+                    tuple(float(v) for v in image_size), mode)
+        fp = _fingerprint(centers, scales, cameras)
+    except (TypeError, KeyError, IndexError, AttributeError, ValueError):
+        call_key = fp = None  # malformed input: the full path below validates and reports
+    if call_key is not None:
+        hit = _TABLES.get(call_key)
+        if hit is not None and hit[0] == fp:
+            return hit[2]
+    table = _pack_cameras(centers, scales, cameras, image_size, mm_mode, B, V)
+    if call_key is not None:
+        if len(_TABLES) >= _TABLES_MAX:
+            _TABLES.clear()
+        # (the lists are kept so that their ids stay theirs; the table is shared: read-only)
+        _TABLES[call_key] = (fp, (list(cameras), list(centers), list(scales)), table)
+    return table
+
+
+def _pack_cameras(centers, scales, cameras, image_size, mm_mode, B, V):
     table = torch.zeros(B, V, CAM_FLOATS, dtype=torch.float32)
     flat = table.view(B * V, CAM_FLOATS)
     params = [cameras[b][v] for b in range(B) for v in range(V)]

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .camera import pack_cameras
+from .camera import pack_cameras, to_device
 
 
 def _pair(v):
@@ -298,7 +298,7 @@ class ProjectLayer(nn.Module):
             axes[2] = axes[2][..., z0:z1].contiguous()
             cube_size = [cube_size[0], cube_size[1], z1 - z0]
         cam_host = pack_cameras(centers, scales, cameras, self.image_size, self.mm_mode)
-        cam = cam_host.to(device)
+        cam = to_device(cam_host, device)
         groups = self._share_groups(cam_host, grid_center, B)
         if groups is not None:
             groups = groups.to(device)
@@ -538,8 +538,8 @@ class ProjectLayerWithMask(nn.Module):
         live = None
         if grid_center.shape[1] != 3:
             live = (grid_center[:, 3] >= 0).to(torch.uint8).contiguous()
-        cam = pack_cameras(centers, scales, cameras, self.image_size,
-                           self.mm_mode).to(device)
+        cam = to_device(pack_cameras(centers, scales, cameras, self.image_size,
+                                     self.mm_mode), device)
         geo = tuple(t.to(torch.int32).contiguous() for t in (centers_tl, start, end))
         return device, B, C, offset, live, cam, geo
 

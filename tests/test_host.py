@@ -135,3 +135,28 @@ def test_share_groups_table():
     assert t.tolist() == [[0, 3], [3, 2], [5, 1], [6, 1]]
     assert ops.share_groups(['a', 'b', 'c']) is None
     assert ops.share_groups(['a'] * 5, max_items=2).tolist() == [[0, 2], [2, 2], [4, 1]]
+
+
+def test_packed_table_cache_sees_replaced_calibrations():
+    """pack_cameras keeps whole tables per call shape (identity of the per-frame lists +
+    a fingerprint of every dict): same inputs -> the same table object; a replaced dict,
+    centre or scale -> a fresh table equal to an uncached packing."""
+    import copy
+    from tempo_amd import camera, synthetic as S
+    cfg = S.PANOPTIC
+    cams = S.ring_cameras(5, seed=3, target=cfg['space_center'])
+    c, s, m = S.frame_meta(cams, 4, cfg['raw_size'], cfg['image_size'])
+    camera.clear_cache()
+    a = camera.pack_cameras(c, s, m, cfg['image_size'])
+    b = camera.pack_cameras(list(c), list(s), list(m), cfg['image_size'])  # new outer lists
+    assert b is a
+    m[2][1] = dict(m[2][1], T=[[10.0], [20.0], [30.0]])
+    d = camera.pack_cameras(c, s, m, cfg['image_size'])
+    assert d is not a and not torch.equal(d, a)
+    assert torch.equal(d[:2], a[:2]) and torch.equal(d[3], a[3])
+    c[1][0] = c[1][0] + 1.0
+    e = camera.pack_cameras(c, s, m, cfg['image_size'])
+    assert e is not d and not torch.equal(e[1, 0], d[1, 0])
+    camera.clear_cache()
+    f = camera.pack_cameras(copy.deepcopy(c), copy.deepcopy(s), copy.deepcopy(m), cfg['image_size'])
+    assert torch.equal(f, e)
