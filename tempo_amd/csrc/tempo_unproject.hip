@@ -277,6 +277,54 @@ __device__ __forceinline__ void planes_epilogue(const UnprojArgs& a, int b, int 
   }
 }
 
+// Masked mean of one wave's tile: every channel value divided by its voxel's denominator
+// (count + 1e-6) -- exact fp32 division through one double multiply (tempo_div_r64);
+// results in the denormal range, where that form can miss an exact tie, are redone with
+// the plain division.  Returns true (wave-uniform) when a NaN or such a result is present
+// anywhere in the wave: the caller then clamps NaN-aware.
+struct DenRec {
+  double r;   // 1 / den
+  float den;  // (float)count + 1e-6f
+  float pad;
+};
+__device__ __forceinline__ DenRec make_den(float den) {
+  DenRec d;
+  d.r = tempo_rcp64_newton(den, tempo_rcp_est(den));
+  d.den = den;
+  d.pad = 0.0f;
+  return d;
+}
+template <int NSUB>
+__device__ __forceinline__ bool normalise_tile(f32x2 (&acc01)[NSUB], f32x2 (&acc23)[NSUB],
+                                               const DenRec (&dr)[NSUB]) {
+  f32x2 q01[NSUB], q23[NSUB];
+  bool odd = false;
+  constexpr int kOdd = 0x001 | 0x002 | 0x010 | 0x080;  // sNaN, qNaN, -denormal, +denormal
+#pragma unroll
+  for (int s = 0; s < NSUB; s++) {
+    q01[s] = tempo_div_r64_2(acc01[s], dr[s].r, dr[s].r);
+    q23[s] = tempo_div_r64_2(acc23[s], dr[s].r, dr[s].r);
+    odd |= __builtin_amdgcn_classf(q01[s].x, kOdd) | __builtin_amdgcn_classf(q01[s].y, kOdd) |
+           __builtin_amdgcn_classf(q23[s].x, kOdd) | __builtin_amdgcn_classf(q23[s].y, kOdd);
+  }
+  const bool slow = __builtin_amdgcn_ballot_w64(odd) != 0;
+  if (slow) {
+#pragma unroll
+    for (int s = 0; s < NSUB; s++) {
+      if (tempo_is_denormal(q01[s].x)) q01[s].x = acc01[s].x / dr[s].den;
+      if (tempo_is_denormal(q01[s].y)) q01[s].y = acc01[s].y / dr[s].den;
+      if (tempo_is_denormal(q23[s].x)) q23[s].x = acc23[s].x / dr[s].den;
+      if (tempo_is_denormal(q23[s].y)) q23[s].y = acc23[s].y / dr[s].den;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NSUB; s++) {
+    acc01[s] = q01[s];
+    acc23[s] = q23[s];
+  }
+  return slow;
+}
+
 template <int MODE>
 __device__ __forceinline__ bool voxel_world(const UnprojArgs& a, int b, int n,
                                             float* x, float* y, float* z) {
@@ -507,8 +555,8 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
   // the denominator belongs to the voxel: one IEEE reciprocal per voxel in the
   // phase A layout, handed to the voxel's L channel lanes through LDS
   {
-    const float den = (MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f;
-    reinterpret_cast<float2*>(wbase)[lane] = make_float2(den, 1.0f / den);
+    reinterpret_cast<DenRec*>(wbase)[lane] =
+        make_den((MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f);
     if (MODE == MODE_ROOT && a.mask != nullptr && n < a.N) {
       char* m = (char*)a.mask + ((long long)b * a.N + n) * a.mask_bytes;
       if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mbits;
@@ -518,25 +566,17 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  float2 dr[NSUB];
+  DenRec dr[NSUB];
 #pragma unroll
   for (int s = 0; s < NSUB; s++) {
     const int vsl = s * VPS + vq;
-    dr[s] = reinterpret_cast<const float2*>(wbase)[(lane_on && vsl < kWaveVox) ? vsl : 0];
+    dr[s] = reinterpret_cast<const DenRec*>(wbase)[(lane_on && vsl < kWaveVox) ? vsl : 0];
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  // exact constant-divisor division on channel pairs; a NaN anywhere in the wave
-  // (torch.clamp keeps it) sends the whole wave through the NaN-aware clamp
-  bool odd = false;
-#pragma unroll
-  for (int s = 0; s < NSUB; s++) {
-    acc01[s] = tempo_div_const2(acc01[s], tempo_splat(dr[s].x), tempo_splat(dr[s].y));
-    acc23[s] = tempo_div_const2(acc23[s], tempo_splat(dr[s].x), tempo_splat(dr[s].y));
-    const f32x2 t = acc01[s] + acc23[s];
-    const float u = t.x + t.y;
-    odd |= u != u;
-  }
+  // exact division; a NaN anywhere in the wave (torch.clamp keeps it) sends the whole
+  // wave through the NaN-aware clamp
+  const bool slow = normalise_tile<NSUB>(acc01, acc23, dr);
   if (a.cmask != nullptr) {
     // torch.clamp's backward passes the gradient where min <= x <= max (NaN: no)
     unsigned long long* mw =
@@ -553,7 +593,6 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
       }
     }
   }
-  const bool slow = __builtin_amdgcn_ballot_w64(odd) != 0;
 #pragma unroll
   for (int s = 0; s < NSUB; s++) {
     const int vsl = s * VPS + vq;
@@ -574,6 +613,31 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+}
+
+// One wave's finished tile -> the volume: value ch of this lane's voxel n is src[ch * tstr]
+// (LDS), its place item[ch * N + n].  One buffer descriptor per batch item, the channel
+// plane in the instruction's scalar offset: per channel one LDS read, one store and one
+// scalar add (as plain pointer arithmetic hipcc spends 4-5 VALU instructions per store on
+// 64-bit addresses).  Volumes of 4 GB and more per item keep the pointer form.
+__device__ __forceinline__ void store_tile(float* item, int C, int N, int n, const float* src,
+                                           int tstr) {
+  const unsigned long long bytes = (unsigned long long)C * (unsigned)N * 4ull;
+  if (bytes < 0x100000000ull) {
+    const unsigned long long p = (unsigned long long)(uintptr_t)item;
+    const unsigned p_lo = __builtin_amdgcn_readfirstlane((unsigned)p);
+    const unsigned p_hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>((uintptr_t)(((unsigned long long)p_hi << 32) | p_lo)), 0,
+        __builtin_amdgcn_readfirstlane((int)(unsigned)bytes), 0x00020000);
+    const unsigned plane = (unsigned)N * 4u;
+    unsigned so = 0;
+    for (int ch = 0; ch < C; ch++, so += plane)
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(src[ch * tstr]), rs,
+                                            (unsigned)n * 4u, so, 0);
+  } else {
+    for (int ch = 0; ch < C; ch++) item[(long long)ch * N + n] = src[ch * tstr];
+  }
 }
 
 // One workgroup of the tile kernel; `bid` is its position in the launch order.
@@ -620,11 +684,10 @@ __device__ __forceinline__ void unproject_block(const UnprojArgs& a, int bid,
   constexpr int TSTR = kWaveVox + 1;
   const float* s_out = reinterpret_cast<const float*>(wbase);
   if (n < a.N && a.cubes != nullptr) {
-    float* dst = a.cubes + (long long)b * a.C * a.N + n;
 #if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 2  // (almost) no stores
     if (s_out[lane] == 123.456f)
 #endif
-    for (int ch = 0; ch < a.C; ch++) dst[(long long)ch * a.N] = s_out[ch * TSTR + lane];
+    store_tile(a.cubes + (long long)b * a.C * a.N, a.C, a.N, n, s_out + lane, TSTR);
   }
   if (a.pl01 != nullptr || a.pl02 != nullptr || a.pl12 != nullptr)
     planes_epilogue(a, b, n0, lane, s_out, TSTR);
@@ -805,7 +868,7 @@ struct __align__(16) GroupRec {
 };
 
 constexpr int group_wave_lds(int V, int L) {
-  return V * kWaveVox * (int)sizeof(GroupRec) + kWaveVox * 8 + 4 * L * (kWaveVox + 1) * 4;
+  return V * kWaveVox * (int)sizeof(GroupRec) + kWaveVox * 16 + 4 * L * (kWaveVox + 1) * 4;
 }
 
 template <int MODE, int L, int UNF>
@@ -833,7 +896,7 @@ __global__ __launch_bounds__(kThreads) void unproject_group_kernel(const UnprojA
 
   unsigned char* wbase = smem + (size_t)wave * a.wave_lds;
   GroupRec* s_rec = reinterpret_cast<GroupRec*>(wbase);  // [V][64]
-  float2* s_den = reinterpret_cast<float2*>(wbase + (size_t)a.V * kWaveVox * sizeof(GroupRec));
+  DenRec* s_den = reinterpret_cast<DenRec*>(wbase + (size_t)a.V * kWaveVox * sizeof(GroupRec));
   constexpr int TSTR = kWaveVox + 1;
   float* s_out = reinterpret_cast<float*>(s_den + kWaveVox);  // [4L][TSTR]
 
@@ -891,8 +954,7 @@ __global__ __launch_bounds__(kThreads) void unproject_group_kernel(const UnprojA
   }
   amask = __builtin_amdgcn_readfirstlane(amask);
   {
-    const float den = (MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f;
-    s_den[lane] = make_float2(den, 1.0f / den);
+    s_den[lane] = make_den((MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -904,7 +966,7 @@ __global__ __launch_bounds__(kThreads) void unproject_group_kernel(const UnprojA
   const int cq = lane - vq * L;
   const unsigned lo = (unsigned)cq * 16u;
   const unsigned rowb = (unsigned)(a.W * CPB);
-  float2 dr[NSUB];
+  DenRec dr[NSUB];
   int rdv[NSUB];
 #pragma unroll
   for (int s = 0; s < NSUB; s++) {
@@ -1015,16 +1077,7 @@ __global__ __launch_bounds__(kThreads) void unproject_group_kernel(const UnprojA
     }
 
     // ---- normalise, clamp, transpose, store (as unproject_kernel's phase C)
-    bool odd = false;
-#pragma unroll
-    for (int s = 0; s < NSUB; s++) {
-      acc01[s] = tempo_div_const2(acc01[s], tempo_splat(dr[s].x), tempo_splat(dr[s].y));
-      acc23[s] = tempo_div_const2(acc23[s], tempo_splat(dr[s].x), tempo_splat(dr[s].y));
-      const f32x2 t = acc01[s] + acc23[s];
-      const float u = t.x + t.y;
-      odd |= u != u;
-    }
-    const bool slow = __builtin_amdgcn_ballot_w64(odd) != 0;
+    const bool slow = normalise_tile<NSUB>(acc01, acc23, dr);
 #pragma unroll
     for (int s = 0; s < NSUB; s++) {
       const int vsl = s * VPS + vq;

@@ -90,47 +90,44 @@ TEMPO_HD tempo_f2 tempo_dot3_2(tempo_f2 a0, tempo_f2 b0, tempo_f2 a1, tempo_f2 b
   return TEMPO_FMA2(a2, b2, TEMPO_FMA2(a1, b1, a0 * b0));
 }
 
-// ---- exact IEEE division without the hardware's scaling preamble.
-// a / b for a divisor known on the host, rb = RN(1/b) (tempo_rcp_rn): one
-// multiply and two FMA correction steps.  The first step leaves q within one
-// ulp; with a correctly rounded reciprocal the second is then correctly rounded
-// (Markstein's theorem), provided no intermediate leaves the normal range --
-// hence the magnitude guard, outside of which the plain division runs.  Checked
-// against a / b over every float in the guarded range for the divisors of the
-// shipped configs (tools/verify_constdiv.c).  One deviation: -0 / b gives +0.
-TEMPO_HD tempo_f2 tempo_div_const2(tempo_f2 a, tempo_f2 b, tempo_f2 rb) {
-  tempo_f2 q = a * rb;
-  tempo_f2 r = TEMPO_FMA2(-b, q, a);
-  q = TEMPO_FMA2(r, rb, q);
-  r = TEMPO_FMA2(-b, q, a);
-  q = TEMPO_FMA2(r, rb, q);
-  // a zero numerator is exact on the fast path; tiny, huge or non-finite ones are not
-  const float m0 = fabsf(a[0]), m1 = fabsf(a[1]);
-  const int ok0 = (m0 == 0.0f) | ((m0 >= 0x1p-100f) & (m0 <= 0x1p100f));
-  const int ok1 = (m1 == 0.0f) | ((m1 >= 0x1p-100f) & (m1 <= 0x1p100f));
-  const int bad = !(ok0 & ok1);
-  if (TEMPO_ANY_LANE(bad)) {
-    const tempo_f2 slow = a / b;
-    if (bad) q = slow;
-  }
+// ---- exact IEEE fp32 division by way of one double-precision multiply.
+// a / b for fp32 a, b and rb = 1/b in double, accurate to about 1 ulp (the host's
+// 1.0 / (double)b, or tempo_rcp64_newton): RN32((double)a * rb) == RN32(a / b).
+// Why: the product carries a relative error below 2^-50.5 (reciprocal 2^-52, product
+// 2^-53).  A quotient of two 24-bit significands A/B that is not itself a rounding
+// boundary m of the fp32 grid (a 25-bit significand M) is at least |A - M*B| / (M*B)
+// >= 2^-49 away from it, relatively, so the error cannot carry the product across a
+// boundary, and it is never ON one for a normal result (M odd cannot divide A < 2^24;
+// the overflow threshold is such a boundary as well).  Zero (of either sign), infinities
+// and NaN go through unchanged; a denormal numerator is exact in double.  Only results
+// in the fp32 DENORMAL range can sit exactly on a tie of the coarser grid there: callers
+// whose result is used as it is (the masked mean) test for a denormal result
+// (tempo_is_denormal) and redo those with the plain division; the sample-grid chain
+// needs no test, because its quotients next go through q * 2 - 1, which rounds to -1
+// for every |q| < 2^-126 alike.  Three full-rate instructions per value (convert,
+// multiply, convert) and no range guard, against five packed-pair steps and a six-compare
+// guard for the two-correction fp32 form this replaces.
+TEMPO_HD float tempo_div_r64(float a, double rb) { return (float)((double)a * rb); }
+TEMPO_HD tempo_f2 tempo_div_r64_2(tempo_f2 a, double rb0, double rb1) {
+  tempo_f2 q = {tempo_div_r64(a[0], rb0), tempo_div_r64(a[1], rb1)};
   return q;
 }
-
-// host side: the float nearest to 1/b (products of two floats are exact in
-// double, so |1 - c*b| ranks the candidates exactly)
-static inline float tempo_rcp_rn(float b) {
-  float y = (float)(1.0 / (double)b);
-  float best = y;
-  double err = fabs(1.0 - (double)y * (double)b);
-  const float cand[2] = {nextafterf(y, -INFINITY), nextafterf(y, INFINITY)};
-  for (int i = 0; i < 2; i++) {
-    const double e = fabs(1.0 - (double)cand[i] * (double)b);
-    if (e < err) {
-      err = e;
-      best = cand[i];
-    }
-  }
-  return best;
+// nonzero with a zero exponent field
+TEMPO_HD int tempo_is_denormal(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_classf(v, 0x010 | 0x080);  // -denormal | +denormal
+#else
+  return v != 0.0f && fabsf(v) < 0x1p-126f;
+#endif
+}
+// 1 / b in double from an fp32 estimate: two Newton steps (2^-23 -> 2^-46 -> below
+// half an ulp of the double)
+TEMPO_HD double tempo_rcp64_newton(float b, float rcp_est) {
+  const double d = (double)b;
+  double r = (double)rcp_est;
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
 }
 
 // [xc, yc] / zc: reciprocal estimate, one Newton step, then the same two
@@ -169,8 +166,8 @@ typedef struct TempoGeom {
   float hm[2];     // the module's heatmap_size (w, h)
   float img[2];    // its image_size (w, h)
   float hm1[2];    // heatmap_size - 1
-  float r_img[2];  // RN(1 / img)
-  float r_hm1[2];  // RN(1 / (heatmap_size - 1))
+  double r_img[2];  // 1 / img
+  double r_hm1[2];  // 1 / (heatmap_size - 1)
 } TempoGeom;
 
 static inline TempoGeom tempo_make_geom(float hm_w, float hm_h, float img_w, float img_h) {
@@ -179,8 +176,8 @@ static inline TempoGeom tempo_make_geom(float hm_w, float hm_h, float img_w, flo
   g.img[0] = img_w; g.img[1] = img_h;
   g.hm1[0] = hm_w - 1.0f; g.hm1[1] = hm_h - 1.0f;
   for (int i = 0; i < 2; i++) {
-    g.r_img[i] = tempo_rcp_rn(g.img[i]);
-    g.r_hm1[i] = tempo_rcp_rn(g.hm1[i]);
+    g.r_img[i] = 1.0 / (double)g.img[i];
+    g.r_hm1[i] = 1.0 / (double)g.hm1[i];
   }
   return g;
 }
@@ -264,10 +261,8 @@ TEMPO_HD void tempo_pixel_to_grid(const TempoCam* cam, float px, float py,
                             tempo_splat(py), tempo_pair(t[2], t[5]), tempo_splat(1.0f),
                             unfused);
   // xy * [w, h] / image_size;  / [w-1, h-1] * 2 - 1
-  a = tempo_div_const2(a * tempo_pair(g->hm[0], g->hm[1]), tempo_pair(g->img[0], g->img[1]),
-                       tempo_pair(g->r_img[0], g->r_img[1]));
-  a = tempo_div_const2(a, tempo_pair(g->hm1[0], g->hm1[1]),
-                       tempo_pair(g->r_hm1[0], g->r_hm1[1]));
+  a = tempo_div_r64_2(a * tempo_pair(g->hm[0], g->hm[1]), g->r_img[0], g->r_img[1]);
+  a = tempo_div_r64_2(a, g->r_hm1[0], g->r_hm1[1]);
   // (a * 2) - 1: the doubling is exact, so one FMA rounds identically
   a = TEMPO_FMA2(a, tempo_splat(2.0f), tempo_splat(-1.0f));
   const float nan = __builtin_nanf("");

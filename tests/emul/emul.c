@@ -63,12 +63,11 @@ static unsigned voxel(const float* hm, const float* cam, int V, int C, int CP,
     }
   }
   const float den = (root ? (float)cnt : (float)V) + 1e-6f;
-  const float rden = 1.0f / den;
-  for (int c = 0; c < C; c += 2) {
-    const tempo_f2 q = tempo_div_const2(tempo_pair(acc[c], c + 1 < C ? acc[c + 1] : 0.0f),
-                                        tempo_splat(den), tempo_splat(rden));
-    out[c] = tempo_nan_clamp(q[0], 0.0f, 1.0f);
-    if (c + 1 < C) out[c + 1] = tempo_nan_clamp(q[1], 0.0f, 1.0f);
+  const double rden = tempo_rcp64_newton(den, tempo_rcp_est(den));
+  for (int c = 0; c < C; c++) {
+    float q = tempo_div_r64(acc[c], rden);
+    if (tempo_is_denormal(q)) q = acc[c] / den;  // as normalise_tile
+    out[c] = tempo_nan_clamp(q, 0.0f, 1.0f);
   }
   return bits;
 }

@@ -14,37 +14,76 @@ import collections
 import re
 import sys
 
-# (file suffix, first line, last line) -> phase; first match wins
-PHASES = [
-    ('unproject_math.h', 82, 91, 'dot3 (X@R, K, affine)'),
-    ('unproject_math.h', 101, 117, 'div_const (image_size, hm-1, mean)'),
-    ('unproject_math.h', 141, 165, 'div_shared (perspective)'),
-    ('unproject_math.h', 211, 225, 'world_to_pixel: camera transform'),
-    ('unproject_math.h', 226, 237, 'world_to_pixel: distortion'),
-    ('unproject_math.h', 238, 249, 'world_to_pixel: K, NaN patch, bounds'),
-    ('unproject_math.h', 253, 276, 'pixel_to_grid: clamp, affine, scale'),
-    ('unproject_math.h', 281, 308, 'bilinear tap: unnormalise, floor, weights'),
-    ('unproject_math.h', 193, 208, 'clamp helpers'),
-    ('unproject_math.h', 63, 80, 'pair helpers'),
-    ('tempo_unproject.hip', 119, 121, 'slot -> view'),
-    ('tempo_unproject.hip', 139, 148, 'map descriptor'),
-    ('tempo_unproject.hip', 157, 165, 'texel offset'),
-    ('tempo_unproject.hip', 176, 187, 'camera record (scalar loads)'),
-    ('tempo_unproject.hip', 207, 278, 'planes epilogue (not run)'),
-    ('tempo_unproject.hip', 281, 313, 'voxel index -> world'),
-    ('tempo_unproject.hip', 319, 358, 'wave prologue'),
-    ('tempo_unproject.hip', 362, 378, 'phase A: need / count / ballot'),
-    ('tempo_unproject.hip', 379, 412, 'phase A: offsets + LDS park'),
-    ('tempo_unproject.hip', 417, 429, 'view loop control'),
-    ('tempo_unproject.hip', 430, 444, 'fetch: LDS read + buffer loads'),
-    ('tempo_unproject.hip', 445, 476, 'mix + view sum'),
-    ('tempo_unproject.hip', 477, 497, 'view loop control'),
-    ('tempo_unproject.hip', 499, 539, 'normalise (reciprocal, LDS hand-over, division)'),
-    ('tempo_unproject.hip', 540, 555, 'clamp mask (training)'),
-    ('tempo_unproject.hip', 556, 577, 'clamp + transpose to LDS'),
-    ('tempo_unproject.hip', 581, 619, 'block prologue / dead items'),
-    ('tempo_unproject.hip', 620, 637, 'volume store'),
+# Phases are found in the sources themselves: (file, regex of the line a phase starts at,
+# phase), searched in file order, each after the previous match; a phase lasts until the
+# next one starts.
+import os
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STARTS = [
+    ('unproject_math.h', r'^TEMPO_HD tempo_f2 tempo_splat', 'pair helpers'),
+    ('unproject_math.h', r'^// sum_k a_k', 'dot3 (X@R, K, affine)'),
+    ('unproject_math.h', r'^// ---- exact IEEE fp32 division', 'div_r64 (image_size, hm-1, mean)'),
+    ('unproject_math.h', r'^// \[xc, yc\] / zc', 'div_shared (perspective)'),
+    ('unproject_math.h', r'^// per-call constants', 'geometry constants'),
+    ('unproject_math.h', r'^TEMPO_HD float tempo_nan_clamp', 'clamp helpers'),
+    ('unproject_math.h', r'^// world point -> source-image pixel', 'world_to_pixel: camera transform'),
+    ('unproject_math.h', r'^  if \(cam->has_dist', 'world_to_pixel: distortion'),
+    ('unproject_math.h', r'^  const float\* K = cam->K;', 'world_to_pixel: K, NaN patch, bounds'),
+    ('unproject_math.h', r'^// source-image pixel -> grid_sample', 'pixel_to_grid: clamp, affine, scale'),
+    ('unproject_math.h', r'^// grid_sample\(align_corners=False\) unnorm', 'bilinear tap: unnormalise, floor, weights'),
+    ('unproject_math.h', r'^// The same footprint as', 'bilinear frac (other kernels)'),
+    ('tempo_unproject.hip', r'^__device__ __forceinline__ int slot_view', 'slot -> view'),
+    ('tempo_unproject.hip', r'^// host side: slot -> view table', 'host'),
+    ('tempo_unproject.hip', r'^// buffer descriptor of one', 'map descriptor'),
+    ('tempo_unproject.hip', r'^// wave-uniform read through', 'uniform loads'),
+    ('tempo_unproject.hip', r'^__device__ __forceinline__ int texel_index', 'texel offset'),
+    ('tempo_unproject.hip', r'^// one byte, wave-uniform', 'uniform loads'),
+    ('tempo_unproject.hip', r'^__device__ __forceinline__ TempoCam load_cam', 'camera record (scalar loads)'),
+    ('tempo_unproject.hip', r'^// maximum over the wave', 'planes epilogue (not run)'),
+    ('tempo_unproject.hip', r"^// Masked mean of one wave's tile", 'normalise: division, class test'),
+    ('tempo_unproject.hip', r'^template <int MODE>$', 'voxel index -> world'),
+    ('tempo_unproject.hip', r"^// One wave's 64 voxels", 'wave prologue'),
+    ('tempo_unproject.hip', r'^  auto phase_a = ', 'phase A: need / count / ballot'),
+    ('tempo_unproject.hip', r'^    if \(active\) \{', 'phase A: offsets + LDS park'),
+    ('tempo_unproject.hip', r"^  // views in torch's summation order", 'view loop control'),
+    ('tempo_unproject.hip', r'^    auto fetch = ', 'fetch: LDS read + buffer loads'),
+    ('tempo_unproject.hip', r'^    auto mix = ', 'mix + view sum'),
+    ('tempo_unproject.hip', r'^    if \(act_cur\) \{', 'view loop control'),
+    ('tempo_unproject.hip', r'^  // -+ phase C', 'normalise: reciprocal, LDS hand-over'),
+    ('tempo_unproject.hip', r'^  if \(a.cmask != nullptr\) \{', 'clamp mask (training)'),
+    ('tempo_unproject.hip', r'^    if \(lane_on && vsl < kWaveVox\) \{', 'clamp + transpose to LDS'),
+    ('tempo_unproject.hip', r"^// One wave's finished tile -> the volume", 'volume store'),
+    ('tempo_unproject.hip', r'^// One workgroup of the tile kernel', 'block prologue / dead items'),
+    ('tempo_unproject.hip', r'^  unproject_wave<MODE, L, SB, UNF>\(a, b, frame', 'volume store'),
+    ('tempo_unproject.hip', r'^// -+ window \+ axis-max planes, fused', 'other kernels'),
 ]
+
+
+def phase_ranges():
+    out = []  # (file suffix, first line, last line, phase)
+    for suf in ('unproject_math.h', 'tempo_unproject.hip'):
+        lines = open(os.path.join(REPO, 'tempo_amd', 'csrc', suf)).read().split('\n')
+        at = 0
+        marks = []
+        for fsuf, rx, ph in STARTS:
+            if fsuf != suf:
+                continue
+            r = re.compile(rx)
+            for i in range(at, len(lines)):
+                if r.match(lines[i]):
+                    marks.append((i + 1, ph))
+                    at = i + 1
+                    break
+            else:
+                raise SystemExit('phase start not found in %s: %s' % (suf, rx))
+        for k, (ln, ph) in enumerate(marks):
+            end = marks[k + 1][0] - 1 if k + 1 < len(marks) else len(lines)
+            out.append((suf, ln, end, ph))
+    return out
+
+
+PHASES = None
 
 
 def unit(op):
@@ -69,6 +108,9 @@ def unit(op):
 
 
 def phase_of(files, fno, line):
+    global PHASES
+    if PHASES is None:
+        PHASES = phase_ranges()
     name = files.get(fno, '?')
     for suf, a, b, ph in PHASES:
         if name.endswith(suf) and a <= line <= b:
