@@ -49,8 +49,21 @@ constexpr int kTileWaves = TEMPO_TILE_WAVES;  // waves per workgroup of the tile
 constexpr int kWaveVox = 64;                // voxels per wave
 // LDS bytes per wave: 2 x 64 records of 32 B while gathering, then the [CP][65]
 // output tile
+// (measurement build -DTEMPO_TIMELINE: + 32 time stamps per wave, written to the `grids`
+// buffer in place of the grids: tools/timeline.py)
+#ifdef TEMPO_TIMELINE
+#define TEMPO_TL(k)                                                        \
+  do {                                                                     \
+    const unsigned long long tl_now = __builtin_readcyclecounter();        \
+    if (lane == 0) reinterpret_cast<unsigned long long*>(wbase + tl_off)[k] = tl_now; \
+  } while (0)
+constexpr int kTimelineBytes = 256;
+#else
+#define TEMPO_TL(k) do {} while (0)
+constexpr int kTimelineBytes = 0;
+#endif
 constexpr int wave_lds_bytes(int L) {
-  return 4 * L * 65 * 4 > 4096 ? 4 * L * 65 * 4 : 4096;
+  return (4 * L * 65 * 4 > 4096 ? 4 * L * 65 * 4 : 4096) + kTimelineBytes;
 }
 // clamp-mask words per 64-voxel tile: one ballot per (sub-step, channel of the quad)
 constexpr int mask_words(int L) { return ((kWaveVox + 64 / L - 1) / (64 / L)) * 4; }
@@ -373,21 +386,28 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
   u32x4* s_off = reinterpret_cast<u32x4*>(wbase);
   float4* s_wt = reinterpret_cast<float4*>(wbase + (size_t)kWaveVox * 32);
   const int n = n0 + lane;  // phase A: this lane's voxel
+#ifdef TEMPO_TIMELINE
+  constexpr int tl_off = wave_lds_bytes(L) - kTimelineBytes;
+  TEMPO_TL(0);
+#endif
 
   float x = 0.f, y = 0.f, z = 0.f;
   const bool have = n < a.N && voxel_world<MODE>(a, b, n, &x, &y, &z);
+#ifndef TEMPO_TIMELINE
   if (MODE == MODE_ROOT && a.grids != nullptr && have) {
     float* g = a.grids + ((long long)b * a.N + n) * 3;
     g[0] = x;
     g[1] = y;
     g[2] = z;
   }
+#endif
 
   // The coordinates came in through vector loads.  Launder them through an empty
   // asm so the waitcnt pass sees them as landed: otherwise it re-waits for
   // "possibly pending" x/y/z at the top of every phase A with vmcnt(0), which
   // also drains the texel fetches that phase A is meant to run under.
   asm volatile("" : "+v"(x), "+v"(y), "+v"(z));
+  TEMPO_TL(1);
 
   // phase B lane roles: L lanes per voxel, VPS voxels per sub-step
   const bool lane_on = lane < VPS * L;
@@ -463,6 +483,7 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
   //   issue the texel fetches of view s  ->  phase A of view s+1 (pure VALU,
   //   runs while the fetches fly)  ->  mix view s.
   bool act_cur = phase_a(0, 0), act_nxt = false;
+  TEMPO_TL(2);
 #pragma unroll 1
   for (int slot = 0; slot < a.V; slot++) {
     const int buf = slot & 1;
@@ -529,8 +550,10 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
       fetch(0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (slot < 8) TEMPO_TL(3 + 3 * slot);
     if (slot + 1 < a.V) act_nxt = phase_a(slot + 1, buf ^ 1);
     __builtin_amdgcn_sched_barrier(0);
+    if (slot < 8) TEMPO_TL(4 + 3 * slot);
     if (act_cur) {
       mix(0);
 #pragma unroll
@@ -542,7 +565,9 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
       }
     }
     act_cur = act_nxt;
+    if (slot < 8) TEMPO_TL(5 + 3 * slot);
   }
+  TEMPO_TL(27);
 
   // ------------------------------------------------------------------ phase C
   // masked mean: sum / (count + 1e-6), clamp; transpose through the wave's LDS
@@ -613,6 +638,7 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  TEMPO_TL(28);
 }
 
 // One wave's finished tile -> the volume: value ch of this lane's voxel n is src[ch * tstr]
@@ -691,6 +717,27 @@ __device__ __forceinline__ void unproject_block(const UnprojArgs& a, int bid,
   }
   if (a.pl01 != nullptr || a.pl02 != nullptr || a.pl12 != nullptr)
     planes_epilogue(a, b, n0, lane, s_out, TSTR);
+#ifdef TEMPO_TIMELINE
+  if (a.grids != nullptr) {
+    constexpr int tl_off = wave_lds_bytes(L) - kTimelineBytes;
+    TEMPO_TL(29);
+    __builtin_amdgcn_s_waitcnt(0);  // stores drained
+    TEMPO_TL(30);
+    unsigned hw_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+    unsigned xcc_id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+    if (lane == 0)
+      reinterpret_cast<unsigned long long*>(wbase + tl_off)[31] =
+          ((unsigned long long)xcc_id << 32) | hw_id;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // 32 stamps of 8 bytes -> the first 256 bytes of this wave's 768 in `grids`
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(
+        a.grids + ((long long)b * a.N + n0) * 3);
+    if (lane < 32) dst[lane] = reinterpret_cast<unsigned long long*>(wbase + tl_off)[lane];
+  }
+#endif
 }
 
 template <int MODE, int L, int SB, int UNF>
