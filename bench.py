@@ -167,9 +167,13 @@ class RootWorkload:
                 memory_format=torch.channels_last) for f in self.fms]
         # frames go through in chunks that reuse one channel-last buffer (ops.root_step);
         # the grouped launch works on the whole batch
-        auto = ops.chunk_frames(self.V, h, w, cp)
+        # (maps read in place: nothing to keep cache-resident between two kernels, one launch
+        # over the whole batch is fastest -- 0.258 ms against 0.282 in 8-frame launches)
+        auto = self.B if self.nhwc else ops.chunk_frames(self.V, h, w, cp)
         self.chunk = self.B if self.groups is not None else min(args.chunk or auto, self.B)
-        self.hm = torch.empty(self.chunk, self.V, h, w, cp, device=dev)
+        self.hm = None if self.nhwc else torch.empty(self.chunk, self.V, h, w, cp, device=dev)
+        self.layouts = {c0: ops.channels_last_layout([f[c0:c0 + n] for f in self.fms])
+                        for c0, n in self._chunks()} if self.nhwc else None
         self.out = torch.empty(self.B, self.J, X, Y, Z, device=dev)
         self.samples = self.B * self.N * self.V
         # volume written once + every heatmap element read once + cameras
@@ -191,8 +195,7 @@ class RootWorkload:
         n = self.chunk if n is None else n
         cfg = self.cfg
         if self.nhwc:
-            lay = self.ops.channels_last_layout([f[c0:c0 + n] for f in self.fms])
-            self.ops.unproject_root_views(lay, self.cam[c0:c0 + n], self.axes, self.J,
+            self.ops.unproject_root_views(self.layouts[c0], self.cam[c0:c0 + n], self.axes, self.J,
                                           cfg['heatmap_size'], cfg['image_size'],
                                           out=self.out[c0:c0 + n])
         else:
@@ -281,14 +284,26 @@ class WindowWorkload:
                                        dtype=torch.int32, device=dev)
         w, h = cfg['heatmap_size']
         cp = ops.padded_channels(self.J)
+        self.input_layout = args.input_layout
+        self.nhwc = args.input_layout != 'nchw'
+        if self.nhwc:
+            if self.groups is not None or args.planes != 'off':
+                raise SystemExit('--input-layout nhwc: plain window volumes only')
+            pad = cp - self.J if args.input_layout == 'nhwc' else 0
+            self.fms = [torch.nn.functional.pad(f, (0, 0, 0, 0, 0, pad)).contiguous(
+                memory_format=torch.channels_last) for f in self.fms]
         # regular batches (window j looks at frame j // P) go through in frame chunks that
         # reuse one channel-last buffer (ops.window_step); sequences / grouped launches do not
         self.P = P
+        self.regular = self.groups is None and (T == 1 or P == 1)
         self.chunk = self.B
         if T == 1 and self.groups is None and args.planes == 'off':  # (planes: one launch is faster)
             self.chunk = min(self.B, args.window_chunk or
                              min(ops.chunk_frames(self.V, h, w, cp), max(1, 40 // P)))
-        self.hm = torch.empty(self.chunk, self.V, h, w, cp, device=dev)
+        self.hm = None if self.nhwc else torch.empty(self.chunk, self.V, h, w, cp, device=dev)
+        # in-place layouts of every chunk's maps, built once (views of the callers' tensors)
+        self.layouts = {f0: ops.channels_last_layout([f[f0:f0 + n] for f in self.fms])
+                        for f0, n in self._chunks()} if self.nhwc else None
         self.N = self.sub[0] * self.sub[1] * self.sub[2]
         self.planes_mode = args.planes
         self.out = (torch.empty(self.NW, self.J, *self.sub, device=dev)
@@ -310,17 +325,34 @@ class WindowWorkload:
         return [(f0, min(self.chunk, self.B - f0)) for f0 in range(0, self.B, self.chunk)]
 
     def repack(self, f0=0, n=None):
+        if self.nhwc:
+            return
         n = self.chunk if n is None else n
         self.ops.repack_nhwc([f[f0:f0 + n] for f in self.fms], out=self.hm[:n])
 
+    def _chunk_args(self, f0, n):
+        key = (f0, n)
+        if key not in self._memo:
+            whole = n == self.B
+            ws = slice(0, self.NW) if whole else slice(f0 * self.P, (f0 + n) * self.P)
+            # inside a chunk the frames are numbered from 0
+            wf = self.win_frame if whole else (self.win_frame[ws] - f0).contiguous()
+            self._memo[key] = (ws, [t[ws] for t in self.geo], wf,
+                               self.cam if whole else self.cam[f0:f0 + n])
+        return self._memo[key]
+
+    _memo = None
+
     def kernel(self, f0=0, n=None):
         n = self.chunk if n is None else n
-        whole = n == self.B
-        ws = slice(0, self.NW) if whole else slice(f0 * self.P, (f0 + n) * self.P)
-        tl, st, en = (t[ws] for t in self.geo)
-        # inside a chunk the frames are numbered from 0
-        wf = self.win_frame if whole else (self.win_frame[ws] - f0).contiguous()
-        cam = self.cam if whole else self.cam[f0:f0 + n]
+        if self._memo is None:
+            self._memo = {}
+        ws, (tl, st, en), wf, cam = self._chunk_args(f0, n)
+        if self.nhwc:  # maps read in place
+            self.ops.unproject_window_views(
+                self.layouts[f0], cam, self.fine, tl, st, en, self.sub, self.J,
+                self.cfg['heatmap_size'], self.cfg['image_size'], win_frame=wf, out=self.out[ws])
+            return
         if self.planes_mode != 'off':
             self.ops.unproject_window_planes(
                 self.hm[:n], cam, self.fine, tl, st, en, self.sub, self.J,
@@ -334,6 +366,14 @@ class WindowWorkload:
                                   win_frame=wf, out=self.out[ws], groups=self.groups)
 
     def step(self):
+        if self.regular and not self.nhwc and self.planes_mode == 'off':
+            # the library's own chunk loop (repack + unprojection per chunk of frames)
+            tl, st, en = self.geo
+            self.ops.window_step(self.fms, self.cam, self.fine, tl, st, en, self.sub,
+                                 self.cfg['heatmap_size'], self.cfg['image_size'],
+                                 windows_per_frame=self.P, out=self.out, chunk=self.chunk,
+                                 hm_buf=self.hm)
+            return
         for f0, n in self._chunks():
             self.repack(f0, n)
             self.kernel(f0, n)
@@ -494,10 +534,18 @@ def measured_traffic(args, wl):
             or args.planes == 'with' or args.share):
         return None, None
     tag = 'root' if args.workload == 'root' else ('planes' if args.planes == 'only' else 'window')
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01',
-                        tag + '_pmc_summary.csv')
-    if (args.batch != 32 or (tag != 'root' and args.proposals != 10) or args.chunk not in (None, 8) or args.channels
-            or not os.path.exists(path)):
+    layout = getattr(wl, 'input_layout', 'nchw')
+    if layout == 'nhwc':
+        tag += '_nhwc'
+    here = os.path.dirname(os.path.abspath(__file__))
+    path = src = None
+    for rnd in ('r02', 'r01'):  # the newest committed profile of this configuration
+        cand = os.path.join(here, 'profiles', rnd, tag + '_pmc_summary.csv')
+        if os.path.exists(cand):
+            path, src = cand, f'profiles/{rnd}/{tag}_pmc_summary.csv'
+            break
+    if (path is None or layout == 'nhwc-tight' or args.batch != 32 or args.chunk is not None
+            or (not tag.startswith('root') and args.proposals != 10) or args.channels):
         return None, None
     vals = {}
     with open(path) as f:
@@ -506,11 +554,29 @@ def measured_traffic(args, wl):
                 vals[row['counter']] = float(row['mean_per_dispatch'])
     if 'FETCH_SIZE' not in vals or 'WRITE_SIZE' not in vals:
         return None, None
-    src = 'profiles/r01/' + tag + '_pmc_summary.csv'
     if 'TCC_HIT_sum' in vals and 'TCC_MISS_sum' in vals:  # L2 hit rate of the same passes
         measured_traffic.l2_hit = round(
             vals['TCC_HIT_sum'] / (vals['TCC_HIT_sum'] + vals['TCC_MISS_sum']), 4)
+    if 'TCP_TOTAL_CACHE_ACCESSES_sum' in vals and 'TCP_TCC_READ_REQ_sum' in vals:
+        # What the texture path allows for this launch's own access mix: its 64-byte L1
+        # accesses priced at the rates the gather microbenchmark sustains on this chip
+        # (profiles/r01/gather_rate_microbenchmark.txt: 0.87 L1 hits, 0.41 L1 misses served by
+        # L2 per clock and CU), 256 CUs at 2.4 GHz, the path busy for the whole launch.
+        miss = vals['TCP_TCC_READ_REQ_sum']
+        hit = max(0.0, vals['TCP_TOTAL_CACHE_ACCESSES_sum'] - miss)
+        measured_traffic.texture_path_ms = (hit / 0.87 + miss / 0.41) / 256 / 2.4e9 * 1e3
     return int((vals['FETCH_SIZE'] + vals['WRITE_SIZE']) * 1024), src
+
+
+def attainable(wl, launches):
+    ms = getattr(measured_traffic, 'texture_path_ms', None)
+    if ms is None:
+        return None
+    gbs = wl.kernel_bytes / launches / (ms * 1e-3) / 1e9
+    return {'kernel_launch_ms': round(ms, 4), 'achieved': round(gbs, 1),
+            'frac': round(gbs / HBM_PEAK_GBS, 4),
+            'bound': 'texture path (TA/TCP): L1 accesses of the profiled launch at the '
+                     'microbenchmarked hit and miss rates'}
 
 
 def free_port():
@@ -643,6 +709,8 @@ def main():
         dist.all_reduce(one)
         seen = int(round(float(one.item())))
 
+    if args.input_layout != 'nchw' and (args.backward or args.planes != 'off' or args.share):
+        raise SystemExit('--input-layout nhwc times the forward volume kernels only')
     wl = DryWorkload() if args.dry_run else make_workload(args, dev, seed=rank)
 
     for _ in range(args.warmup):
@@ -840,6 +908,10 @@ def main():
                 'step_frac': round(step_achieved / HBM_PEAK_GBS, 4),
                 'limiter': getattr(wl, 'limiter', None),
                 'l2_hit_rate': getattr(measured_traffic, 'l2_hit', None),
+                # speed of light of this formulation: the launch's texel accesses at the
+                # texture path's measured hit / miss rates; null when
+                # the profiled counters of this configuration are not committed
+                'attainable': attainable(wl, launches),
                 'kernel': wl.kernel_name, 'kernel_ms': round(k_ms, 4),
                 'launches_per_step': launches,
                 'kernel_launch_ms': round(k_ms / launches, 4),

@@ -223,6 +223,21 @@ def chunk_frames(V, H, W, cp, limit=ROOT_CHUNK_FRAMES):
     return int(max(1, min(limit, CHUNK_BYTES // (V * H * W * cp * 4))))
 
 
+_WIN_FRAME = {}
+
+
+def _regular_win_frame(frames, per_frame, dev):
+    """int32 ``[frames * per_frame]``: window j looks at frame ``j // per_frame`` (cached: the
+    chunk loop of :func:`window_step` asks for the same two tables every step)."""
+    key = (frames, per_frame, str(dev))
+    if key not in _WIN_FRAME:
+        if len(_WIN_FRAME) > 64:
+            _WIN_FRAME.clear()
+        _WIN_FRAME[key] = (torch.arange(frames * per_frame, device=dev, dtype=torch.int32)
+                           // per_frame).contiguous()
+    return _WIN_FRAME[key]
+
+
 def window_step(feature_maps, cam, fine_axes, tl, start, end, sub_cube, heatmap_size,
                 image_size, windows_per_frame=1, c_begin=0, channels=None, live=None,
                 out=None, planes_out=None, planes=False, want_cubes=True, mm_mode='auto',
@@ -260,9 +275,7 @@ def window_step(feature_maps, cam, fine_axes, tl, start, end, sub_cube, heatmap_
         n = min(chunk, F_ - f0)
         fs, ws = slice(f0, f0 + n), slice(f0 * P, (f0 + n) * P)
         hm = repack_nhwc([fm[fs] for fm in feature_maps], c_begin, C, out=hm_buf[:n])
-        wf = None
-        if P != 1:
-            wf = (torch.arange(n * P, device=dev, dtype=torch.int32) // P).contiguous()
+        wf = None if P == 1 else _regular_win_frame(n, P, dev)
         lv = None if live is None else live[ws]
         if planes:
             unproject_window_planes(hm, cam[fs], fine_axes, tl[ws], start[ws], end[ws], sub_cube,
