@@ -226,6 +226,10 @@ class RootWorkload:
         steps = min(steps, 10)
         E = lambda: torch.cuda.Event(enable_timing=True)
         ks, rs = [], []
+        for c0, n in self._chunks():  # (first use of these entry points: not timed)
+            self.repack(c0, n)
+            self.kernel(c0, n)
+        torch.cuda.synchronize()
         keep = gpu_blocker(self.dev)
         for _ in range(steps):
             for c0, n in self._chunks():
@@ -299,7 +303,7 @@ class WindowWorkload:
         self.chunk = self.B
         if T == 1 and self.groups is None and args.planes == 'off':  # (planes: one launch is faster)
             self.chunk = min(self.B, args.window_chunk or
-                             min(ops.chunk_frames(self.V, h, w, cp), max(1, 40 // P)))
+                             (self.B if self.nhwc else ops.chunk_frames(self.V, h, w, cp)))
         self.hm = None if self.nhwc else torch.empty(self.chunk, self.V, h, w, cp, device=dev)
         # in-place layouts of every chunk's maps, built once (views of the callers' tensors)
         self.layouts = {f0: ops.channels_last_layout([f[f0:f0 + n] for f in self.fms])
@@ -408,6 +412,7 @@ class DenseWorkload:
         args.batch, args.calibrations = 1, 1
         # every rank holds the same frame (replicated heatmaps): same seed on all ranks
         self.cfg, self.fms, self.cam, _ = make_inputs(args, dev, 0, cfg)
+        self.meta = make_inputs.meta
         self.B, self.V, self.J = 1, 10, cfg['num_joints']
         self.world = int(os.environ.get('WORLD_SIZE', '1'))
         rank = int(os.environ.get('RANK', '0'))

@@ -41,6 +41,13 @@ namespace {
 #ifndef TEMPO_SB_WINDOW
 #define TEMPO_SB_WINDOW 1
 #endif
+// Cache policy of the volume stores: 2 = `nt` (streaming).  The volume is written once and
+// read by nobody in this launch; with the default policy its lines displace the heatmaps
+// from L2 and the Infinity Cache (config 2, maps read in place: 0.267 -> 0.240 ms; repacked
+// in 16-frame chunks 0.262 -> 0.211 ms; sc0 / sc1 change nothing)
+#ifndef TEMPO_STORE_AUX
+#define TEMPO_STORE_AUX 2
+#endif
 constexpr int kThreads = 256;
 #ifndef TEMPO_TILE_WAVES
 #define TEMPO_TILE_WAVES 4
@@ -660,7 +667,7 @@ __device__ __forceinline__ void store_tile(float* item, int C, int N, int n, con
     unsigned so = 0;
     for (int ch = 0; ch < C; ch++, so += plane)
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(src[ch * tstr]), rs,
-                                            (unsigned)n * 4u, so, 0);
+                                            (unsigned)n * 4u, so, TEMPO_STORE_AUX);
   } else {
     for (int ch = 0; ch < C; ch++) item[(long long)ch * N + n] = src[ch * tstr];
   }
@@ -828,10 +835,8 @@ __global__ __launch_bounds__(kPlaneWaves * 64) void unproject_planes_kernel(
   for (int x = x_begin; x < x_end; x++) {
     const int n0 = (x * VY + y) * kWaveVox;
     unproject_wave<MODE_WINDOW, L, SB, UNF>(a, b, frame, n0, lane, wbase);
-    if (a.cubes != nullptr) {
-      float* dst = a.cubes + (long long)b * a.C * a.N + n0 + lane;
-      for (int ch = 0; ch < a.C; ch++) dst[(long long)ch * a.N] = s_out[ch * TSTR + lane];
-    }
+    if (a.cubes != nullptr)
+      store_tile(a.cubes + (long long)b * a.C * a.N, a.C, a.N, n0 + lane, s_out + lane, TSTR);
     const int xs = (x - x_begin) % kPlaneXB;
 #pragma unroll
     for (int ch = 0; ch < CH; ch++) {
@@ -1150,7 +1155,7 @@ __global__ __launch_bounds__(kThreads) void unproject_group_kernel(const UnprojA
       if (dead) {
         for (int ch = 0; ch < a.C; ch++) dst[(long long)ch * a.N] = 0.0f;
       } else {
-        for (int ch = 0; ch < a.C; ch++) dst[(long long)ch * a.N] = s_out[ch * TSTR + lane];
+        store_tile(a.cubes + (long long)b * a.C * a.N, a.C, a.N, n, s_out + lane, TSTR);
       }
       if (MODE == MODE_ROOT && a.grids != nullptr) {
         float* gp = a.grids + ((long long)b * a.N + n) * 3;
@@ -1650,8 +1655,13 @@ __device__ __forceinline__ void repack_wide_block(const RepackArgs& a, int bx, i
   for (int k = 0; k < L; k++) {
     const int c = wave + 4 * k;
     r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (c < a.C && p < a.HW)
-      r[k] = *reinterpret_cast<const float4*>(in + (long long)c * a.HW + p);
+    if (c < a.C && p < a.HW) {
+      // read once: streaming policy, so the planes do not displace the chunk being gathered
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const f32x4 t = __builtin_nontemporal_load(
+          reinterpret_cast<const f32x4*>(in + (long long)c * a.HW + p));
+      r[k] = make_float4(t.x, t.y, t.z, t.w);
+    }
   }
 #pragma unroll
   for (int k = 0; k < L; k++) {

@@ -213,8 +213,12 @@ def unproject_window_backward(grad_cubes, cam, fine_axes, tl, start, end, clamp_
     return ghm
 
 
-ROOT_CHUNK_FRAMES = 8
-CHUNK_BYTES = 100e6  # channel-last maps of one chunk: well inside the 256 MB Infinity Cache
+# channel-last maps of one chunk stay in the 256 MB Infinity Cache between the repack that
+# writes them and the gather that reads them; the volume goes out with streaming stores and
+# does not compete for it (measured at config 2: 8 / 12 / 16 / 32 frames per chunk
+# 0.315 / 0.297 / 0.279 / 0.375 ms per 32-frame step)
+ROOT_CHUNK_FRAMES = 16
+CHUNK_BYTES = 170e6
 
 
 def chunk_frames(V, H, W, cp, limit=ROOT_CHUNK_FRAMES):
@@ -258,8 +262,9 @@ def window_step(feature_maps, cam, fine_axes, tl, start, end, sub_cube, heatmap_
     if NW != F_ * P:
         raise ValueError('window_step needs windows_per_frame windows for every frame, in order')
     cp = padded_channels(C)
-    if chunk is None:  # cache-sized, and about 40 windows per launch (measured best)
-        chunk = min(chunk_frames(V, H, W, cp), max(1, 40 // P))
+    if chunk is None:  # cache-sized (config 3: 2 / 4 / 8 / 16 / 32 frames per chunk
+        # 3.73 / 3.60 / 3.57 / 3.55 / 3.76 ms per step)
+        chunk = chunk_frames(V, H, W, cp)
         if planes:  # the column-walk kernel has long workgroups: one launch is faster
             chunk = F_
     chunk = int(chunk)
@@ -300,18 +305,18 @@ def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, chan
               live=None, want_grids=False, want_mask=False, out=None, mm_mode='auto',
               chunk=None, hm_buf=None, in_library=True, zmax_out=None):
     """Repack + root unprojection of a whole batch, in chunks of ``chunk`` frames
-    (default 8) that reuse one channel-last buffer: the 80 MB a chunk's maps take
-    stay in the 256 MB Infinity Cache between the repack that writes them and the
-    gather that reads them, instead of making a round trip through HBM (config 2:
-    0.39 -> 0.31 ms per 32-frame step; 8 frames also give each of the 8 XCDs one
-    frame).  Arguments as :func:`repack_nhwc` + :func:`unproject_root`; ``axes``
-    and ``live`` may be per batch item.  Returns ``(cubes, grids | None, mask | None)``."""
+    (default :func:`chunk_frames`: 16 at config 2) that reuse one channel-last buffer: a
+    chunk's maps stay in the 256 MB Infinity Cache between the repack that writes them and
+    the gather that reads them, instead of making a round trip through HBM (config 2:
+    0.39 -> 0.28 ms per 32-frame step).  Arguments as :func:`repack_nhwc` +
+    :func:`unproject_root`; ``axes`` and ``live`` may be per batch item.  Returns
+    ``(cubes, grids | None, mask | None)``."""
     fm0 = feature_maps[0]
     dev = fm0.device
     B, C_total, H, W = fm0.shape
     V = len(feature_maps)
     C = C_total - c_begin if channels is None else channels
-    chunk = ROOT_CHUNK_FRAMES if chunk is None else int(chunk)
+    chunk = chunk_frames(V, H, W, padded_channels(C)) if chunk is None else int(chunk)
     X, Y, Z = (int(a.shape[-1]) for a in axes)
     N = X * Y * Z
     if out is None:

@@ -356,7 +356,7 @@ class ProjectLayer(nn.Module):
         if source == 'packed' and self.keep_zmax:
             zmax = torch.empty(B, C, cubes.shape[2], cubes.shape[3], dtype=torch.float32,
                                device=cubes.device)
-        chunk = ops.ROOT_CHUNK_FRAMES
+        chunk = B  # maps read where they lie: one launch over the batch is fastest
         for c0, cs in _Slices(C).items:
             first = c0 == 0
             out = cubes if cs == C else torch.empty(B, cs, *cubes.shape[2:], dtype=torch.float32,
