@@ -133,8 +133,9 @@ def gpu_blocker(dev, ms=12.0):
 
 class RootWorkload:
     name = 'panoptic_cam5_root_80x80x20_b32'
-    limiter = ('texture path: 16 texel fetches per wave and view at the L1-miss rate '
-               '(DESIGN.md section 4)')
+    limiter = ('texture path (TA/TCP), saturated in steady state: 4 x 64-byte texel accesses '
+               'per sample at 0.87 (L1 hit) / 0.41 (L1 miss, L2 hit) accesses per clock and CU; '
+               'see roofline.attainable and DESIGN.md section 4')
 
     def __init__(self, args, dev, seed):
         from tempo_amd import ops, project_layer as PL
