@@ -1805,7 +1805,9 @@ __global__ __launch_bounds__(kThreads) void conv1x1_nhwc_kernel(const ConvArgs a
     f32x4 x = {0.f, 0.f, 0.f, 0.f};
     if (k0 + kq < a.K) {
       if (a.vec) {
-        if (px < a.HW) x = *reinterpret_cast<const f32x4*>(q);
+        // (read once, 5 GB at config 2's shape: streaming policy, so the maps being
+        // written stay cached for the unprojection that follows)
+        if (px < a.HW) x = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(q));
       } else {
 #pragma unroll
         for (int e = 0; e < 4; e++)

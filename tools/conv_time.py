@@ -56,13 +56,16 @@ def hip_conv():
 
 def hip_chain():
     ops.conv1x1_nhwc(x, wt, bias, num_views=V, out=hm)
-    for c0 in range(0, B, 8):
-        ops.unproject_root(hm[c0:c0 + 8], wl.cam[c0:c0 + 8], wl.axes, J, cfg['heatmap_size'],
-                           cfg['image_size'], out=out_b[c0:c0 + 8])
+    ops.unproject_root(hm, wl.cam, wl.axes, J, cfg['heatmap_size'], cfg['image_size'], out=out_b)
+
+
+def hip_unproject_only():
+    ops.unproject_root(hm, wl.cam, wl.axes, J, cfg['heatmap_size'], cfg['image_size'], out=out_b)
 
 
 res = {'torch_conv2d_ms': timed(ref_conv), 'hip_conv1x1_nhwc_ms': timed(hip_conv),
        'torch_conv_plus_root_step_ms': timed(ref_chain), 'hip_conv_plus_unproject_ms': timed(hip_chain),
+       'hip_unproject_alone_ms': timed(hip_unproject_only),
        'input_GB': x.numel() * 4 / 1e9}
 res['hip_conv_GBps'] = res['input_GB'] / res['hip_conv1x1_nhwc_ms'] * 1e3
 res['volume_max_abs_diff'] = float((out_a - out_b).abs().max())
