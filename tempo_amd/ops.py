@@ -218,7 +218,7 @@ def unproject_window_backward(grad_cubes, cam, fine_axes, tl, start, end, clamp_
 # does not compete for it (measured at config 2: 8 / 12 / 16 / 32 frames per chunk
 # 0.315 / 0.297 / 0.279 / 0.375 ms per 32-frame step)
 ROOT_CHUNK_FRAMES = 16
-CHUNK_BYTES = 170e6
+CHUNK_BYTES = 190e6  # (16 Panoptic frames = 157 MB; 4 H36M frames = 189 MB: 3 / 4 / 8 frames 4.26 / 4.03 / 4.72 ms)
 
 
 def chunk_frames(V, H, W, cp, limit=ROOT_CHUNK_FRAMES):
