@@ -1,43 +1,53 @@
-"""Does repack(chunk c+1) overlap unproject(chunk c) on two streams?  (root workload)"""
-import argparse, os, sys, time
+"""Root step, NCHW input: does repack(chunk c+1) overlap unproject(chunk c) on two streams with
+two alternating channel-last buffers?  (Re-measured in round 2 with streaming stores.)"""
+import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-ap = argparse.ArgumentParser()
-ap.add_argument('--batch', type=int, default=32)
-ap.add_argument('--workload', default='root')
-ap.add_argument('--proposals', type=int, default=10)
-a = ap.parse_args()
 dev = torch.device('cuda:0')
+a = bench.parse(['--no-cpu-baseline'])
 wl = bench.RootWorkload(a, dev, seed=0)
-ops = wl.ops
-sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+ops, cfg = wl.ops, wl.cfg
+sR, sU = torch.cuda.Stream(), torch.cuda.Stream()
+h, w = cfg['heatmap_size'][1], cfg['heatmap_size'][0]
+cp = ops.padded_channels(wl.J)
 
-def step_chunks(K):
-    B = wl.B
-    step = B // K
-    evs = []
-    main = torch.cuda.current_stream()
-    sA.wait_stream(main); sB.wait_stream(main)
-    for c in range(K):
-        b0, b1 = c * step, (c + 1) * step
-        with torch.cuda.stream(sA):
-            ops.repack_nhwc([f[b0:b1] for f in wl.fms], out=wl.hm[b0:b1])
-            e = torch.cuda.Event(); e.record(sA)
-        with torch.cuda.stream(sB):
-            sB.wait_event(e)
-            ops.unproject_root(wl.hm[b0:b1], wl.cam[b0:b1], wl.axes, wl.J, wl.cfg['heatmap_size'],
-                               wl.cfg['image_size'], out=wl.out[b0:b1])
-    main.wait_stream(sA); main.wait_stream(sB)
 
-def timeit(fn, n=30):
+def piped(chunk):
+    bufs = [torch.empty(chunk, wl.V, h, w, cp, device=dev) for _ in range(2)]
+    done = [None, None]  # event: the unprojection that last read the buffer
+
+    def step():
+        main = torch.cuda.current_stream()
+        sR.wait_stream(main); sU.wait_stream(main)
+        for i, c0 in enumerate(range(0, wl.B, chunk)):
+            n = min(chunk, wl.B - c0)
+            buf = bufs[i & 1]
+            with torch.cuda.stream(sR):
+                if done[i & 1] is not None:
+                    sR.wait_event(done[i & 1])
+                ops.repack_nhwc([f[c0:c0 + n] for f in wl.fms], out=buf[:n])
+                e = torch.cuda.Event(); e.record(sR)
+            with torch.cuda.stream(sU):
+                sU.wait_event(e)
+                ops.unproject_root(buf[:n], wl.cam[c0:c0 + n], wl.axes, wl.J, cfg['heatmap_size'],
+                                   cfg['image_size'], out=wl.out[c0:c0 + n])
+                d = torch.cuda.Event(); d.record(sU)
+                done[i & 1] = d
+        main.wait_stream(sR); main.wait_stream(sU)
+    return step
+
+
+def timeit(fn, n=40):
     for _ in range(5): fn()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
+
 wl.step(); ref = wl.out.clone()
-print('sequential ms', round(timeit(wl.step), 4))
-for K in (1, 2, 4, 8):
-    wl.out.zero_(); step_chunks(K); torch.cuda.synchronize()
-    print('chunks', K, 'ms', round(timeit(lambda: step_chunks(K)), 4), 'equal', torch.equal(ref, wl.out))
+print('one stream, library chunk loop (chunk %d): %.4f ms' % (wl.chunk, timeit(wl.step)))
+for chunk in (4, 8, 16):
+    st = piped(chunk)
+    wl.out.zero_(); st(); torch.cuda.synchronize()
+    print('two streams, chunk %2d: %.4f ms  equal %s' % (chunk, timeit(st), torch.equal(ref, wl.out)))
