@@ -117,3 +117,32 @@ def test_flavour_probe_is_consistent():
     assert all(v in ('fma', 'unfused') for v in m.values())
     assert numerics.probe(n=4096) == m
     assert numerics.abi_flag('fma') == 0 and numerics.abi_flag('unfused') == 7
+
+
+def _extreme_maps(case):
+    """Heatmap channels scaled into the fp32 denormal range, up to the overflow threshold, with
+    a NaN and an infinity planted: the masked mean's division then runs its denormal-quotient
+    and NaN paths (normalise_tile / tempo_div_r64 in the kernels)."""
+    fms = [f.clone() for f in case['args'][0]]
+    scales = [1e-38, 3e-41, 2e-44, 1.0, 3e38, 1e-45, 7e-40]
+    for f in fms:
+        for c in range(f.shape[1]):
+            f[:, c] *= scales[c % len(scales)]
+    H, W = fms[0].shape[2:]
+    fms[0][0, 3, H // 3:H // 2, W // 3:W // 2] = float('nan')
+    fms[-1][0, 10, H // 2:2 * H // 3, W // 2:2 * W // 3] = float('inf')
+    out = dict(case)
+    out['args'] = (fms,) + tuple(case['args'][1:])
+    return out
+
+
+def test_root_contract_extreme_values_bit_exact(emul):
+    case = _extreme_maps(cases.build_root('root_panoptic_noise'))
+    layer = O.ProjectLayer(case['image_size'], case['heatmap_size'])
+    ref, _ = layer(*case['args'])
+    got, _ = E.run_root(emul, case)
+    r = ref.numpy()
+    assert np.isnan(r).any() and (np.abs(r[np.isfinite(r)]) < 1.2e-38).any()  # both paths hit
+    assert np.array_equal(np.isnan(got), np.isnan(r))
+    assert np.array_equal(np.nan_to_num(got, nan=-1.0).view(np.uint32),
+                          np.nan_to_num(r, nan=-1.0).view(np.uint32))

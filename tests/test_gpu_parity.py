@@ -486,3 +486,30 @@ def test_root_zmax_equals_torch_max(name, gpu_device):
     canon = lambda t: torch.nan_to_num(t, nan=-1.0)
     assert layer.last_zmax.shape == cubes.shape[:4]
     assert torch.equal(canon(layer.last_zmax), canon(cubes.max(dim=4)[0]))
+
+
+@pytest.mark.parametrize('variant', ['root', 'window'])
+def test_extreme_heatmap_values_bit_exact(variant, gpu_device):
+    """Channels scaled into the fp32 denormal range and up to the overflow threshold, a NaN
+    patch and an infinity patch: the masked mean's double-precision division must round like
+    the oracle's fp32 division everywhere (denormal quotients are redone with the plain
+    division, NaN and inf pass through), bit for bit."""
+    import tempo_amd
+    from test_contract import _extreme_maps
+    if variant == 'root':
+        case = _extreme_maps(cases.build_root('root_panoptic_noise'))
+        ref, _ = O.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')(*case['args'])
+        layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    else:
+        case = _extreme_maps(cases.build_window('win_h36m_noise'))
+        ref, _ = O.ProjectLayerWithMask(case['image_size'], case['heatmap_size'],
+                                        'mean')(*case['args'])
+        layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    with torch.no_grad():
+        got, _ = layer(*cases.to_device(case, gpu_device)['args'])
+    got, ref = got.cpu().numpy(), ref.numpy()
+    assert np.isnan(ref).any() and (np.abs(ref[np.isfinite(ref)]) < 1.2e-38).any()
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    same = np.nan_to_num(got, nan=-1.0).view(np.uint32) == np.nan_to_num(ref, nan=-1.0).view(np.uint32)
+    print(f'[extreme {variant}] differing elements: {int((~same).sum())} of {same.size}')
+    assert same.all()
