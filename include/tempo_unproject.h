@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define TEMPO_ABI_VERSION 7
+#define TEMPO_ABI_VERSION 8
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
@@ -367,6 +367,22 @@ int tempo_unrepack_nchw(const float* in, void* const* views, int V, int B,
 int tempo_conv1x1_nhwc(const float* in, const float* weight, const float* bias, float* out,
                        int T, int V, int B, int K, int C, int CP, int H, int W,
                        void* stream);
+
+/* Integer window geometry of ProjectLayerWithMask.get_voxel, project_layer.py:299-324, for
+ * all windows of a call in one launch: centers_tl = round(gc[:, :3] * scale + bias).int(),
+ * offset = centers_tl / (fine - 1) * space - space / 2 + sub / 2, the bbox mask
+ * ((1 - gc[:, 5:7]) / 2 * (vox[:2] - 1)).int() clamped at 0, start / end (:316-324), and the
+ * skip flag gc[:, 3] >= 0 (:232).  Every fp32 step is rounded like the reference's separate
+ * tensor ops: results are bit-identical to them.
+ *   grid_center : fp32 [B, cols], cols == 3 (no bbox, no skip rule) or >= 7
+ *   scale, bias, space_size, sub_space_size : DEVICE fp32 [3] (the module's own tensors,
+ *                 set_space_size :184-201)
+ *   tl, start, end : int32 [B, 3];  offset : fp32 [B, 3];  live : uint8 [B] or NULL */
+int tempo_window_geometry(const float* grid_center, int B, int cols, const float* scale,
+                          const float* bias, const float* space_size,
+                          const float* sub_space_size, int FX, int FY, int FZ, int VX, int VY,
+                          int VZ, int32_t* tl, int32_t* start, int32_t* end, float* offset,
+                          uint8_t* live, void* stream);
 
 /* z-columns of the root volume at K (x, y) cells per frame -- what the detector's 1-D
  * stage reads (tempo_detector.py:204-206: torch.gather(torch.flatten(cubes, 2, 3)

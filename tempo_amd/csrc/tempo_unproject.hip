@@ -1885,6 +1885,67 @@ __global__ __launch_bounds__(kThreads) void zcolumns_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------- window geometry
+// project_layer.py:299-324 for all windows of a call in one launch (the reference spends
+// about fifteen tiny tensor ops on it, per candidate and timestep).  One thread per window;
+// every fp32 step is the separately rounded torch op of the reference (this file is built
+// with -ffp-contract=off; divisions are correctly rounded), so the integers and the offset
+// are bit-identical to the tensor-op form (tests/test_gpu_layouts.py).
+struct GeomArgs {
+  const float* gc;     // [B][cols] proposals (x, y, z, id, conf, bbox_w, bbox_h)
+  const float* scale;  // [3] (fine - 1) / space          (set_space_size)
+  const float* bias;   // [3]
+  const float* space;  // [3] whole_space_size
+  const float* sub;    // [3] ind_space_size
+  int fine[3], vox[3];
+  int B, cols;
+  int32_t* tl;
+  int32_t* start;
+  int32_t* end;
+  float* offset;
+  uint8_t* live;  // or nullptr
+};
+
+__global__ __launch_bounds__(kThreads) void window_geometry_kernel(const GeomArgs a) {
+  const int b = blockIdx.x * kThreads + threadIdx.x;
+  if (b >= a.B) return;
+  const float* g = a.gc + (long long)b * a.cols;
+  int tl[3], mask[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    float t = g[i] * a.scale[i];
+    t = t + a.bias[i];
+    tl[i] = (int)rintf(t);  // torch.round: half to even
+    float o = (float)tl[i] / (float)(a.fine[i] - 1);
+    o = o * a.space[i];
+    o = o - a.space[i] / 2.0f;
+    o = o + a.sub[i] / 2.0f;
+    a.tl[3 * b + i] = tl[i];
+    a.offset[3 * b + i] = o;
+  }
+  if (a.cols >= 7) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      float m = 1.0f - g[5 + j];
+      m = m / 2.0f;
+      m = m * (float)(a.vox[j] - 1);
+      const int mi = (int)m;  // .int(): towards zero
+      mask[j] = mi < 0 ? 0 : mi;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int lo = tl[i] + mask[i];
+    const int st = lo >= 0 ? lo : 0;
+    const int hi = tl[i] + a.vox[i] - mask[i];
+    int en = hi <= a.fine[i] ? hi : a.fine[i];
+    en = en > st + 1 ? en : st + 1;
+    a.start[3 * b + i] = st;
+    a.end[3 * b + i] = en;
+  }
+  if (a.live != nullptr) a.live[b] = (a.cols > 3 && !(g[3] >= 0.0f)) ? 0 : 1;
+}
+
 // ---------------------------------------------------------- project points
 __global__ __launch_bounds__(kThreads) void project_points_kernel(
     const float* __restrict__ pts, const float* __restrict__ cam, int N,
@@ -2707,6 +2768,29 @@ int tempo_conv1x1_nhwc(const float* in, const float* weight, const float* bias, 
     hipLaunchKernelGGL((conv1x1_nhwc_kernel<1>), grid, dim3(kThreads), lds, (hipStream_t)stream, a);
   else
     hipLaunchKernelGGL((conv1x1_nhwc_kernel<2>), grid, dim3(kThreads), lds, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int tempo_window_geometry(const float* grid_center, int B, int cols, const float* scale,
+                          const float* bias, const float* space_size,
+                          const float* sub_space_size, int FX, int FY, int FZ, int VX, int VY,
+                          int VZ, int32_t* tl, int32_t* start, int32_t* end, float* offset,
+                          uint8_t* live, void* stream) {
+  if (!grid_center || !scale || !bias || !space_size || !sub_space_size || !tl || !start ||
+      !end || !offset)
+    return TEMPO_E_NULL;
+  if (B <= 0 || (cols != 3 && cols < 7) || FX <= 1 || FY <= 1 || FZ <= 1 || VX <= 0 ||
+      VY <= 0 || VZ <= 0)
+    return TEMPO_E_DIM;
+  GeomArgs a = {};
+  a.gc = grid_center; a.scale = scale; a.bias = bias; a.space = space_size;
+  a.sub = sub_space_size;
+  a.fine[0] = FX; a.fine[1] = FY; a.fine[2] = FZ;
+  a.vox[0] = VX; a.vox[1] = VY; a.vox[2] = VZ;
+  a.B = B; a.cols = cols;
+  a.tl = tl; a.start = start; a.end = end; a.offset = offset; a.live = live;
+  hipLaunchKernelGGL(window_geometry_kernel, dim3((B + kThreads - 1) / kThreads), dim3(kThreads),
+                     0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

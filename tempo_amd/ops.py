@@ -822,3 +822,34 @@ def conv1x1_nhwc(x, weight, bias, num_views, timesteps=1, out=None):
                                     H, W, _stream_ptr(dev))
     _lib.check(rc, 'tempo_conv1x1_nhwc')
     return out
+
+
+def window_geometry(grid_center, scale, bias, space_size, sub_space_size, fine_bins, sub_cube,
+                    want_live=True):
+    """``project_layer.py:299-324`` for all windows of a call in one launch
+    (``tempo_window_geometry``): returns ``(centers_tl, offset, start, end, live | None)``,
+    bit-identical to the reference's tensor ops.  ``grid_center`` fp32 ``[B, 3 | >=7]`` on the
+    device; ``scale`` / ``bias`` / ``space_size`` / ``sub_space_size`` device fp32 ``[3]``."""
+    lib = _lib.load()
+    dev = grid_center.device
+    _need(grid_center, torch.float32, 'grid_center')
+    B, cols = grid_center.shape
+    for name, t in (('scale', scale), ('bias', bias), ('space_size', space_size),
+                    ('sub_space_size', sub_space_size)):
+        _need(t, torch.float32, name, dev)
+        if t.numel() != 3:
+            raise ValueError(f'{name} must have 3 entries')
+    tl = torch.empty(B, 3, dtype=torch.int32, device=dev)
+    start = torch.empty_like(tl)
+    end = torch.empty_like(tl)
+    offset = torch.empty(B, 3, dtype=torch.float32, device=dev)
+    live = torch.empty(B, dtype=torch.uint8, device=dev) if (want_live and cols != 3) else None
+    fx, fy, fz = (int(v) for v in fine_bins)
+    vx, vy, vz = (int(v) for v in sub_cube)
+    with torch.cuda.device(dev):
+        rc = lib.tempo_window_geometry(_ptr(grid_center), B, cols, _ptr(scale), _ptr(bias),
+                                       _ptr(space_size), _ptr(sub_space_size), fx, fy, fz, vx,
+                                       vy, vz, _ptr(tl), _ptr(start), _ptr(end), _ptr(offset),
+                                       _ptr(live), _stream_ptr(dev))
+    _lib.check(rc, 'tempo_window_geometry')
+    return tl, offset, start, end, live

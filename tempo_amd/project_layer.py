@@ -460,7 +460,13 @@ class ProjectLayerWithMask(nn.Module):
 
     def set_space_size(self, space_center, space_size, sub_space_size,
                        sub_cube_size, device):
-        """``project_layer.py:184-201``, same tensor ops on ``device``."""
+        """``project_layer.py:184-201``, same tensor ops on ``device`` (skipped when the
+        arguments are the ones of the previous call: the pose regressor calls with the same
+        geometry for every candidate and timestep)."""
+        key = (tuple(space_center), tuple(space_size), tuple(sub_space_size),
+               tuple(sub_cube_size), str(device))
+        if getattr(self, '_space_key', None) == key:
+            return
         self.whole_space_center = torch.tensor(space_center, device=device)
         self.whole_space_size = torch.tensor(space_size, device=device)
         self.ind_space_size = torch.tensor(sub_space_size, device=device)
@@ -484,6 +490,11 @@ class ProjectLayerWithMask(nn.Module):
         self._sub_cube = [int(v) for v in vpa]
         self._fine_bins = [int(v) for v in ((ws / ins * (vpa - 1)).int() + 1)]
         self._space = (list(space_center), list(space_size), list(sub_space_size))
+        # fp32 copies for tempo_window_geometry (integer configs give int64 tensors above; the
+        # reference's ops promote them to fp32 operand by operand: same values)
+        self._wss_f = self.whole_space_size.float().contiguous()
+        self._iss_f = self.ind_space_size.float().contiguous()
+        self._space_key = key
 
     def compute_grid(self, box_size, box_center, num_bins, device=None):
         return ProjectLayer.compute_grid(self, box_size, box_center, num_bins, device)
@@ -533,11 +544,20 @@ class ProjectLayerWithMask(nn.Module):
         B, C = _batch_channels(feature_maps)
         if grid_center.device != device:
             grid_center = grid_center.to(device)
-        centers_tl, offset, start, end = self.window_geometry(grid_center)
+        cols = grid_center.shape[1]
+        if (grid_center.dtype == torch.float32 and grid_center.is_contiguous()
+                and self.scale.dtype == torch.float32 and self.bias.dtype == torch.float32
+                and cols >= 7):
+            # one launch instead of the reference's fifteen tensor ops (bit-identical)
+            centers_tl, offset, start, end, live = ops.window_geometry(
+                grid_center, self.scale, self.bias, self._wss_f, self._iss_f,
+                self._fine_bins, self._sub_cube)
+        else:
+            centers_tl, offset, start, end = self.window_geometry(grid_center)
+            live = None
+            if grid_center.shape[1] != 3:
+                live = (grid_center[:, 3] >= 0).to(torch.uint8).contiguous()
         self._ensure_grids(device)
-        live = None
-        if grid_center.shape[1] != 3:
-            live = (grid_center[:, 3] >= 0).to(torch.uint8).contiguous()
         cam = to_device(pack_cameras(centers, scales, cameras, self.image_size,
                                      self.mm_mode), device)
         geo = tuple(t.to(torch.int32).contiguous() for t in (centers_tl, start, end))

@@ -124,3 +124,14 @@ def test_misaligned_channel_last_buffers_are_rejected():
     assert lib.tempo_root_step(ptrs, 15, 0, one, one, one, one, 0, None, one, None, None, 0, 1,
                                2, 15, 16, 8, 8, 4, 4, 4, 8.0, 8.0, 8.0, 8.0, 0, odd, 1,
                                None) == -5
+
+
+def test_window_geometry_rejects_bad_arguments():
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    one = P(16)
+    geo = lambda **kw: lib.tempo_window_geometry(
+        kw.get('gc', one), kw.get('B', 4), kw.get('cols', 7), one, one, one, one,
+        kw.get('FX', 253), 253, 64, 64, 64, 64, kw.get('tl', one), one, one, one, None, None)
+    assert geo(gc=None) == -1 and geo(tl=None) == -1
+    assert geo(B=0) == -2 and geo(cols=5) == -2 and geo(FX=1) == -2

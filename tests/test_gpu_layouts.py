@@ -222,3 +222,39 @@ def test_process_layer_nhwc_feeds_the_project_layer(gpu_device):
     xg = x.to(dev).requires_grad_(True)
     lists = layer2d(xg, num_views=V, timesteps=T)
     assert isinstance(lists[0], list) and lists[0][0].shape == (B, C, 32, 60)
+
+
+@pytest.mark.parametrize('cols', [7, 9])
+def test_window_geometry_kernel_equals_the_tensor_ops(cols, gpu_device):
+    """tempo_window_geometry against the reference-shaped tensor ops of
+    ProjectLayerWithMask.window_geometry (project_layer.py:299-324): integers, offset and
+    skip flags bit for bit, including proposals outside the space, half-way rounding cases
+    and bounding boxes wider than the window."""
+    import tempo_amd
+    from tempo_amd import ops, synthetic as S
+    cfg = S.PANOPTIC
+    layer = tempo_amd.ProjectLayerWithMask(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    layer.set_space_size(cfg['space_center'], cfg['space_size'], cfg['sub_space_size'],
+                         cfg['sub_cube_size'], gpu_device)
+    g = torch.Generator().manual_seed(5)
+    B = 4096
+    gc = torch.zeros(B, cols)
+    span = torch.tensor(cfg['space_size'], dtype=torch.float32)
+    gc[:, :3] = (torch.rand(B, 3, generator=g) * 1.6 - 0.8) * span + \
+        torch.tensor(cfg['space_center'], dtype=torch.float32)
+    # exact half-way cases of the rounding: (k + 0.5 - bias) / scale
+    k = torch.arange(0, 200, dtype=torch.float32)
+    gc[:200, 0] = (k + 0.5 - layer.bias.cpu()[0]) / layer.scale.cpu()[0]
+    if cols >= 7:
+        gc[:, 3] = torch.randint(-1, 4, (B,), generator=g).float()
+        gc[:, 4] = torch.rand(B, generator=g)
+        gc[:, 5:7] = torch.rand(B, 2, generator=g) * 2.4 - 0.7  # also < 0 and > 1
+    gc = gc.to(gpu_device)
+    tl, off, st, en = layer.window_geometry(gc)
+    tl2, off2, st2, en2, live2 = ops.window_geometry(
+        gc, layer.scale, layer.bias, layer._wss_f, layer._iss_f, layer._fine_bins,
+        layer._sub_cube)
+    assert torch.equal(tl.to(torch.int32), tl2) and torch.equal(st.to(torch.int32), st2)
+    assert torch.equal(en.to(torch.int32), en2)
+    assert torch.equal(off.view(torch.int32), off2.view(torch.int32))
+    assert torch.equal((gc[:, 3] >= 0).to(torch.uint8), live2)
