@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench, tempo_amd
-args = bench.parse(['--workload', 'root', '--no-cpu-baseline'])
+args = bench.parse(["--workload", "root", "--no-cpu-baseline", "--batch", os.environ.get("B", "32")])
 dev = torch.device('cuda:0')
 wl = bench.RootWorkload(args, dev, 0)
 cfg = wl.cfg
