@@ -15,6 +15,28 @@ def _stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_STAGING = {}
+
+
+def _staging(dev, numel):
+    """A persistent fp32 staging buffer of at least ``numel`` elements for the current stream
+    of ``dev`` (the channel-last maps of one chunk: written and read inside one call, dead
+    afterwards).  Kept across calls, grow-only, instead of asking the caching allocator for
+    ~100 MB per call.  One buffer per (device, stream): calls on different streams do not
+    share it."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(dev).cuda_stream)
+    buf = _STAGING.get(key)
+    if buf is None or buf.numel() < numel:
+        buf = None
+        _STAGING.pop(key, None)
+        if len(_STAGING) > 16:
+            _STAGING.clear()
+        buf = torch.empty(int(numel), dtype=torch.float32, device=dev)
+        _STAGING[key] = buf
+    return buf
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -275,7 +297,8 @@ def window_step(feature_maps, cam, fine_axes, tl, start, end, sub_cube, heatmap_
         planes_out = [torch.empty(NW, C, *sh, dtype=torch.float32, device=dev)
                       for sh in ((vx, vy), (vx, vz), (vy, vz))]
     if hm_buf is None:
-        hm_buf = torch.empty(min(chunk, F_), V, H, W, cp, dtype=torch.float32, device=dev)
+        n0 = min(chunk, F_)
+        hm_buf = _staging(dev, n0 * V * H * W * cp)[:n0 * V * H * W * cp].view(n0, V, H, W, cp)
     for f0 in range(0, F_, chunk):
         n = min(chunk, F_ - f0)
         fs, ws = slice(f0, f0 + n), slice(f0 * P, (f0 + n) * P)
@@ -338,7 +361,8 @@ def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, chan
         return out, grids, mask
     cp = padded_channels(C)
     if hm_buf is None:
-        hm_buf = torch.empty(chunk, V, H, W, cp, dtype=torch.float32, device=dev)
+        hm_buf = _staging(dev, chunk * V * H * W * cp)[:chunk * V * H * W * cp].view(
+            chunk, V, H, W, cp)
     batched = axes[0].dim() == 2
     for c0 in range(0, B, chunk):
         n = min(chunk, B - c0)
@@ -394,7 +418,7 @@ def _root_step_library(feature_maps, cam, axes, heatmap_size, image_size, c_begi
         raise ValueError('out has the wrong size')
     need = int(lib.tempo_root_step_workspace(B, V, H, W, cp, chunk))
     if workspace is None or workspace.numel() < need:
-        workspace = torch.empty(need, dtype=torch.float32, device=dev)
+        workspace = _staging(dev, need)
     _need(workspace, torch.float32, 'workspace', dev)
     mask_bytes = 0 if mask is None else mask_dtype(V)[0]
     ptrs = (ctypes.c_void_p * V)(*[fm.data_ptr() for fm in keep])
