@@ -21,6 +21,11 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, int tile_words)
         __hip_atomic_fetch_add(&tile[a], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else if (MODE == 1) {
         tile[a] += v;  // plain read-add-write (races between waves: timing only)
+      } else if (MODE == 3) {  // integer max (what the fused axis-max planes use)
+        __hip_atomic_fetch_max(reinterpret_cast<unsigned*>(&tile[a]), __float_as_uint(v) + u,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (MODE == 4) {  // plain store
+        tile[a] = v;
       } else {  // every lane of the instruction on ONE word per 16 lanes (same-address lanes)
         __hip_atomic_fetch_add(&tile[(a & ~63u) + (lane >> 4)], v, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -58,6 +63,8 @@ int main() {
     run<0>("ds_add_f32 distinct words", waves, 32768);
     run<1>("plain read+add+write", waves, 32768);
     run<2>("ds_add_f32 16 lanes per word", waves, 32768);
+    run<3>("ds_max_u32 distinct words", waves, 32768);
+    run<4>("plain ds_write_b32", waves, 32768);
   }
   return 0;
 }
