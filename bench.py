@@ -240,9 +240,14 @@ class RootWorkload:
                 rs.append((r0, r1)); ks.append((k0, k1))
         torch.cuda.synchronize()
         del keep
-        k_ms = sum(a.elapsed_time(b) for a, b in ks) / steps
-        r_ms = sum(a.elapsed_time(b) for a, b in rs) / steps
-        return k_ms, r_ms, len(self._chunks())
+        # per step: the sum over its launches; the median step (a clock dip of a few ms --
+        # seen on these boxes -- then costs one sample, not the mean)
+        per = len(self._chunks())
+        ksum = sorted(sum(a.elapsed_time(b) for a, b in ks[i * per:(i + 1) * per])
+                      for i in range(steps))
+        rsum = sorted(sum(a.elapsed_time(b) for a, b in rs[i * per:(i + 1) * per])
+                      for i in range(steps))
+        return ksum[steps // 2], rsum[steps // 2], per
 
 
 class WindowWorkload:
