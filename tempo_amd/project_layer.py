@@ -395,7 +395,7 @@ class ProjectLayer(nn.Module):
     def forward_sequence(self, feature_maps_t, grid_size, grid_center_t, cube_size,
                          centers_t, scales_t, cameras_t):
         """Extension: the detector's loop over ``time_idx``
-        (``tempo_detector.py:175-191``) in one launch.  Every argument that the
+        (``tempo_detector.py:175-191``) in one call.  Every argument that the
         reference indexes with ``time_idx`` is a list over T here:
         ``feature_maps_t[t][v]`` = ``[B,C,H,W]``, ``grid_center_t[t]`` = the
         ``[space_center]`` list of timestep t, ``centers_t[t][b][v]`` etc.  Returns
@@ -406,8 +406,6 @@ class ProjectLayer(nn.Module):
         if any(_wants_grad(f) for f in feature_maps_t):
             raise NotImplementedError('forward_sequence is forward-only; loop over forward()')
         B, C = feature_maps_t[0][0].shape[:2]
-        V = len(feature_maps_t[0])
-        H, W = feature_maps_t[0][0].shape[2:]
         ax, lives = [], []
         for t in range(T):
             a, cs = self._axes(grid_size, grid_center_t[t], cube_size, B, device)
@@ -419,16 +417,18 @@ class ProjectLayer(nn.Module):
         cam = torch.cat([pack_cameras(centers_t[t], scales_t[t], cameras_t[t], self.image_size,
                                       self.mm_mode) for t in range(T)], 0).to(device)
         cubes = torch.empty(T * B, C, *cs, dtype=torch.float32, device=device)
+        # one library call per timestep: its chunk loop keeps a chunk's channel-last maps
+        # cached between the repack and the gather (one launch over all T*B frames reads
+        # them back from HBM: 0.34 against 0.27 ms per 32 frames at config 2)
         for c0, n in _Slices(C).items:
-            cp = ops.padded_channels(n)
-            hm = torch.empty(T * B, V, H, W, cp, dtype=torch.float32, device=device)
-            for t in range(T):  # every timestep repacks straight into its slice
-                ops.repack_nhwc(feature_maps_t[t], c0, n, out=hm[t * B:(t + 1) * B])
-            out, _, _ = ops.unproject_root(hm, cam, axes, n, self.heatmap_size, self.image_size,
-                                           live=live, out=cubes if n == C else None,
-                                           mm_mode=self.mm_mode)
-            if n != C:
-                cubes[:, c0:c0 + n] = out
+            for t in range(T):
+                sl = slice(t * B, (t + 1) * B)
+                out, _, _ = ops.root_step(
+                    feature_maps_t[t], cam[sl], [a[sl] for a in axes], self.heatmap_size,
+                    self.image_size, c_begin=c0, channels=n, live=live[sl],
+                    out=cubes[sl] if n == C else None, mm_mode=self.mm_mode)
+                if n != C:
+                    cubes[sl, c0:c0 + n] = out
         return cubes
 
 
