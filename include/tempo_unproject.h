@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define TEMPO_ABI_VERSION 8
+#define TEMPO_ABI_VERSION 9
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
@@ -140,6 +140,18 @@ int tempo_root_step(const void* const* views, int C_total, int c_begin,
                     int V, int C, int CP, int H, int W, int X, int Y, int Z,
                     float hm_w, float hm_h, float img_w, float img_h,
                     int mm_unfused, float* workspace, int chunk, void* stream);
+
+/* tempo_root_step that also returns the volume's maximum over z (what CenterNet
+ * computes first, center_net.py:230), as tempo_unproject_root_zmax does per chunk.
+ *   zmax : out fp32 [B, C, X, Y], bit-identical to torch.max(cubes, dim=4) */
+int tempo_root_step_zmax(const void* const* views, int C_total, int c_begin,
+                         const float* cam, const float* ax_x, const float* ax_y,
+                         const float* ax_z, int ax_batched, const uint8_t* live,
+                         float* cubes, float* grids, void* mask, int mask_bytes, int B,
+                         int V, int C, int CP, int H, int W, int X, int Y, int Z,
+                         float hm_w, float hm_h, float img_w, float img_h,
+                         int mm_unfused, float* zmax, float* workspace, int chunk,
+                         void* stream);
 
 /* tempo_root_step that allocates nothing and takes no workspace.  NO COUNTERPART IN
  * THE REFERENCE: it exists for callers that cannot call hipMalloc or bring a

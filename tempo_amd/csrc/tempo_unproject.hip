@@ -238,6 +238,32 @@ __device__ __forceinline__ void voxel_index(const UnprojArgs& a, int n, int* i0,
   *i0 = (int)q0;
 }
 
+// Root z-max alone: voxels per wave when waves are made of whole z-columns (every column's
+// maximum is then complete inside one wave and is stored, not max-accumulated), or 64 when
+// columns do not fit a wave or more than 1/8 of the lanes would idle.
+__host__ __device__ inline int zmax_wave_vox(int Z) {
+  if (Z >= kWaveVox) return kWaveVox;
+  const int w = (kWaveVox / Z) * Z;
+  return (kWaveVox - w) * 8 <= kWaveVox ? w : kWaveVox;
+}
+
+// z-max planes of a dead item in whole-column mode (nothing else clears them)
+__device__ __forceinline__ void zmax_clear_columns(const UnprojArgs& a, int b, int n0,
+                                                   int lane) {
+  const int Z = a.dim[2];
+  const int cols = a.wave_vox / Z;
+  for (int s0 = 0; s0 < cols * a.C; s0 += kWaveVox) {
+    const int slot = s0 + lane;
+    const int c = slot / a.C, ch = slot - c * a.C;
+    const int nc = n0 + c * Z;
+    if (c < cols && nc < a.N) {
+      int j0, j1, j2;
+      voxel_index(a, nc, &j0, &j1, &j2);
+      a.pl01[(((long long)b * a.C + ch) * a.dim[0] + j0) * a.dim[1] + j1] = 0u;
+    }
+  }
+}
+
 // Fused axis-max epilogue: the finished [C][64 voxels] tile of one wave (s_out,
 // lane = voxel) goes into the three max-projection planes the pose regressor
 // builds from the window volume (tempo_pose.py:172-176; center_net.py:230 for
@@ -742,6 +768,8 @@ __device__ __forceinline__ void unproject_block(const UnprojArgs& a, int bid,
         for (int k = 0; k < a.mask_bytes; k++) m[k] = 0;
       }
     }
+    if (MODE == MODE_ROOT && a.pl01 != nullptr && a.wave_vox != kWaveVox)
+      zmax_clear_columns(a, b, n0, lane);
     return;
   }
 
@@ -2043,9 +2071,8 @@ int launch_one(const UnprojArgs& a, hipStream_t stream) {
   // atomics (config 2: 60 of 64 lanes busy; the fused z-max then costs +0.01 instead of
   // +0.06 ms per step)
   if (MODE == MODE_ROOT && a.pl01 != nullptr && a.pl02 == nullptr && a.pl12 == nullptr &&
-      a.cmask == nullptr && a.dim[2] < kWaveVox &&
-      (kWaveVox - (kWaveVox / a.dim[2]) * a.dim[2]) * 8 <= kWaveVox)  // <= 1/8 of the lanes idle
-    k.wave_vox = (kWaveVox / a.dim[2]) * a.dim[2];
+      a.cmask == nullptr)
+    k.wave_vox = zmax_wave_vox(a.dim[2]);
   k.tile_vox = kTileWaves * k.wave_vox;
   k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
   const long long total = (long long)a.NB * k.tiles;
@@ -2522,10 +2549,14 @@ int root_impl(const Layout& lay, const float* cam, const float* ax_x, const floa
     if (e != hipSuccess) return (int)e;
     return launch_backward<MODE_ROOT>(a, mm_unfused, (hipStream_t)stream);
   }
-  if (ex.zmax != nullptr) {  // max-accumulated: starts at +0.0, the smallest clamped value
-    const hipError_t e = hipMemsetAsync(ex.zmax, 0, (size_t)B * C * X * Y * sizeof(float),
-                                        (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
+  if (ex.zmax != nullptr) {
+    // max-accumulated with atomics: starts at +0.0, the smallest clamped value; waves of
+    // whole columns (launch_one) store every entry themselves, dead items included
+    if (groups != nullptr || a.cmask != nullptr || zmax_wave_vox(Z) == kWaveVox) {
+      const hipError_t e = hipMemsetAsync(ex.zmax, 0, (size_t)B * C * X * Y * sizeof(float),
+                                          (hipStream_t)stream);
+      if (e != hipSuccess) return (int)e;
+    }
     a.pl01 = reinterpret_cast<unsigned*>(ex.zmax);
   }
   return launch_mode<MODE_ROOT>(a, mm_unfused, (hipStream_t)stream);
@@ -2540,12 +2571,16 @@ long long tempo_root_step_workspace(int B, int V, int H, int W, int CP, int chun
   return (long long)(B < chunk ? B : chunk) * V * H * W * CP;
 }
 
-int tempo_root_step(const void* const* views, int C_total, int c_begin, const float* cam,
-                    const float* ax_x, const float* ax_y, const float* ax_z, int ax_batched,
-                    const uint8_t* live, float* cubes, float* grids, void* mask,
-                    int mask_bytes, int B, int V, int C, int CP, int H, int W, int X, int Y,
-                    int Z, float hm_w, float hm_h, float img_w, float img_h, int mm_unfused,
-                    float* workspace, int chunk, void* stream) {
+}  // extern "C"
+
+namespace {
+
+int root_step_impl(const void* const* views, int C_total, int c_begin, const float* cam,
+                   const float* ax_x, const float* ax_y, const float* ax_z, int ax_batched,
+                   const uint8_t* live, float* cubes, float* grids, void* mask,
+                   int mask_bytes, int B, int V, int C, int CP, int H, int W, int X, int Y,
+                   int Z, float hm_w, float hm_h, float img_w, float img_h, int mm_unfused,
+                   float* zmax, float* workspace, int chunk, void* stream) {
   if (views == nullptr || workspace == nullptr || cam == nullptr || cubes == nullptr)
     return TEMPO_E_NULL;
   const int rc = check_common(V, C, CP, H, W);
@@ -2567,6 +2602,8 @@ int tempo_root_step(const void* const* views, int C_total, int c_begin, const fl
       shifted[v] = static_cast<const float*>(views[v]) + (long long)b0 * C_total * HW;
     err = tempo_repack_nhwc(shifted, V, n, C_total, c_begin, C, H, W, CP, workspace, stream);
     if (err != TEMPO_OK) break;
+    Extra ex;
+    ex.zmax = zmax ? zmax + (long long)b0 * C * X * Y : nullptr;
     err = root_impl(workspace, cam + (long long)b0 * V * CAM_FLOATS,
                     ax_x + (ax_batched ? (long long)b0 * X : 0),
                     ax_y + (ax_batched ? (long long)b0 * Y : 0),
@@ -2575,9 +2612,37 @@ int tempo_root_step(const void* const* views, int C_total, int c_begin, const fl
                     grids ? grids + (long long)b0 * N * 3 : nullptr,
                     mask ? static_cast<char*>(mask) + (long long)b0 * N * mask_bytes : nullptr,
                     mask_bytes, n, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w, img_h,
-                    mm_unfused, nullptr, 0, Extra(), stream);
+                    mm_unfused, nullptr, 0, ex, stream);
   }
   return err;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tempo_root_step(const void* const* views, int C_total, int c_begin, const float* cam,
+                    const float* ax_x, const float* ax_y, const float* ax_z, int ax_batched,
+                    const uint8_t* live, float* cubes, float* grids, void* mask,
+                    int mask_bytes, int B, int V, int C, int CP, int H, int W, int X, int Y,
+                    int Z, float hm_w, float hm_h, float img_w, float img_h, int mm_unfused,
+                    float* workspace, int chunk, void* stream) {
+  return root_step_impl(views, C_total, c_begin, cam, ax_x, ax_y, ax_z, ax_batched, live, cubes,
+                        grids, mask, mask_bytes, B, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w,
+                        img_h, mm_unfused, nullptr, workspace, chunk, stream);
+}
+
+int tempo_root_step_zmax(const void* const* views, int C_total, int c_begin, const float* cam,
+                         const float* ax_x, const float* ax_y, const float* ax_z,
+                         int ax_batched, const uint8_t* live, float* cubes, float* grids,
+                         void* mask, int mask_bytes, int B, int V, int C, int CP, int H, int W,
+                         int X, int Y, int Z, float hm_w, float hm_h, float img_w, float img_h,
+                         int mm_unfused, float* zmax, float* workspace, int chunk,
+                         void* stream) {
+  if (zmax == nullptr) return TEMPO_E_NULL;
+  return root_step_impl(views, C_total, c_begin, cam, ax_x, ax_y, ax_z, ax_batched, live, cubes,
+                        grids, mask, mask_bytes, B, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w,
+                        img_h, mm_unfused, zmax, workspace, chunk, stream);
 }
 
 }  // extern "C"

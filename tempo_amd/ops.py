@@ -347,12 +347,12 @@ def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, chan
     grids = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if want_grids else None
     mask = torch.empty(B, N, dtype=mask_dtype(V)[1], device=dev) if want_mask else None
     if zmax_out is not None:
-        in_library = False  # (the z-max rides on the per-chunk call)
+        _need(zmax_out, torch.float32, 'zmax_out', dev)
         if tuple(zmax_out.shape) != (B, C, X, Y):
             raise ValueError(f'zmax_out must be [{B},{C},{X},{Y}]')
     if in_library:  # the same chunk loop inside the library: one call, no per-chunk host work
         return _root_step_library(feature_maps, cam, axes, heatmap_size, image_size, c_begin, C,
-                                live, out, grids, mask, mm_mode, chunk, hm_buf)
+                                live, out, grids, mask, mm_mode, chunk, hm_buf, zmax_out)
     if B <= chunk:
         hm = repack_nhwc(feature_maps, c_begin, C, out=None if hm_buf is None else hm_buf[:B])
         unproject_root(hm, cam, axes, C, heatmap_size, image_size, live=live,
@@ -385,8 +385,9 @@ def root_step_workspace(B, V, H, W, cp, chunk, device):
 
 
 def _root_step_library(feature_maps, cam, axes, heatmap_size, image_size, c_begin, C, live, out,
-                     grids, mask, mm_mode, chunk, workspace):
-    """``tempo_root_step``: the chunk loop of :func:`root_step` inside the library."""
+                     grids, mask, mm_mode, chunk, workspace, zmax=None):
+    """``tempo_root_step`` (``tempo_root_step_zmax`` with ``zmax``): the chunk loop of
+    :func:`root_step` inside the library."""
     lib = _lib.load()
     fm0 = feature_maps[0]
     dev = fm0.device
@@ -422,14 +423,19 @@ def _root_step_library(feature_maps, cam, axes, heatmap_size, image_size, c_begi
     _need(workspace, torch.float32, 'workspace', dev)
     mask_bytes = 0 if mask is None else mask_dtype(V)[0]
     ptrs = (ctypes.c_void_p * V)(*[fm.data_ptr() for fm in keep])
-    with torch.cuda.device(dev):
-        rc = lib.tempo_root_step(
-            ptrs, C_total, c_begin, _ptr(cam), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]),
+    head = (ptrs, C_total, c_begin, _ptr(cam), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]),
             int(batched), _ptr(live), _ptr(out), _ptr(grids), _ptr(mask), mask_bytes, B, V, C,
             cp, H, W, X, Y, Z, float(heatmap_size[0]), float(heatmap_size[1]),
-            float(image_size[0]), float(image_size[1]), numerics.abi_flag(mm_mode),
-            _ptr(workspace), int(chunk), _stream_ptr(dev))
-    _lib.check(rc, 'tempo_root_step')
+            float(image_size[0]), float(image_size[1]), numerics.abi_flag(mm_mode))
+    with torch.cuda.device(dev):
+        if zmax is None:
+            rc = lib.tempo_root_step(*head, _ptr(workspace), int(chunk), _stream_ptr(dev))
+        else:
+            if not zmax.is_contiguous():
+                raise ValueError('zmax_out must be contiguous')
+            rc = lib.tempo_root_step_zmax(*head, _ptr(zmax), _ptr(workspace), int(chunk),
+                                          _stream_ptr(dev))
+    _lib.check(rc, 'tempo_root_step' if zmax is None else 'tempo_root_step_zmax')
     return out, grids, mask
 
 

@@ -471,6 +471,16 @@ def test_root_step_library_loop_equals_separate_calls(gpu_device):
         for a, b in zip(got, ref):
             assert torch.equal(torch.nan_to_num(a.float(), nan=-1.0),
                                torch.nan_to_num(b.float(), nan=-1.0)), (chunk, lib)
+        # the same step with the fused z-max (tempo_root_step_zmax / per-chunk calls): every
+        # entry is written, the dead item's included, whatever the buffer held before
+        zmax = torch.full((B, cfg['num_joints'], cube[0], cube[1]), 7.0, device=gpu_device)
+        got = ops.root_step(fms, cam, axes, cfg['heatmap_size'], cfg['image_size'], live=live,
+                            chunk=chunk, in_library=lib, zmax_out=zmax)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.nan_to_num(got[0], nan=-1.0), torch.nan_to_num(ref[0], nan=-1.0))
+        assert torch.equal(torch.nan_to_num(zmax, nan=-1.0),
+                           torch.nan_to_num(ref[0].max(dim=4)[0], nan=-1.0)), (chunk, lib)
+        assert not zmax[2].any()
 
 
 @pytest.mark.parametrize('name', list(cases.ROOT_CASES))
