@@ -1393,15 +1393,18 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
 // as above: the tile is an accelerator, never a correctness condition.
 // Config 3, ms per launch: 108.9 per-sample kernel; square 10 x 10 tile 26.9; box-shaped
 // rows 24.2; 81 texels (14 waves per CU) 22.6; 12-byte voxel records (16 waves) 21.0;
-// gradient loads issued together 20.2.
+// gradient loads issued together 20.2.  Tile size (round 2; config 3 / H36M slice, ms):
+// 64 texels 22.9 / -, 81 20.7 / 5.96, 100 19.7 / 5.39, 121 19.8 / 5.00, 144 21.1 / 4.67 --
+// a brick whose box does not fit is done as two halves, which costs more than the waves
+// the larger tile displaces (12 instead of 16 per CU), up to about 1.5x the mean box.
 #ifndef TEMPO_BRICK_CAP
-#define TEMPO_BRICK_CAP 81
+#define TEMPO_BRICK_CAP 121
 #endif
 constexpr int kBrickCap = TEMPO_BRICK_CAP;  // texels per tile
 struct BrickLds {
   int tile, stage, rec, total;
 };
-// CP = 16: 81 * 64 + 16 * 65 * 4 + 64 * 12 = 10112 bytes, 16 waves per CU
+// CP = 16: 121 * 64 + 16 * 65 * 4 + 64 * 12 = 12672 bytes, 12 waves per CU
 constexpr BrickLds brick_lds(int L) {
   BrickLds l{};
   l.tile = 0;
