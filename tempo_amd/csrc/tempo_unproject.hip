@@ -1457,6 +1457,8 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
 
   // incoming gradient (lane = voxel), divided by the view count and zeroed where
   // the forward's clamp blocks it, parked as [channel][voxel]
+  float x = 0.f, y = 0.f, z = 0.f;
+  bool have = false;
   {
     const float* gout = a.cubes + (long long)b * a.C * a.N;
     const float den = (float)a.V + 1e-6f;
@@ -1475,6 +1477,11 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
 #pragma unroll
     for (int ch = 0; ch < CP; ch++) gv[ch] = gout[(long long)(ch < a.C ? ch : 0) * a.N + nn];
     __builtin_amdgcn_sched_barrier(0);
+    // (while the loads are under way: clear the tile, find the voxels' world points)
+    for (int i = lane; i < CAP * CP; i += 64) tile[i] = 0.0f;
+    have = inb && voxel_world<MODE>(a, b, n, &x, &y, &z);
+    if (__builtin_amdgcn_ballot_w64(have) == 0) return;
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ch = 0; ch < CP; ch++) {
       const int cq = ch >> 2, j = ch & 3;
@@ -1482,10 +1489,6 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
       st[ch * TSTR + lane] = open ? gv[ch] / den : 0.0f;
     }
   }
-  for (int i = lane; i < CAP * CP; i += 64) tile[i] = 0.0f;
-  float x = 0.f, y = 0.f, z = 0.f;
-  const bool have = inb && voxel_world<MODE>(a, b, n, &x, &y, &z);
-  if (__builtin_amdgcn_ballot_w64(have) == 0) return;
 
   // step layout: TP footprint texels x CP channels per instruction
   constexpr int TP = 64 / CP >= 4 ? 4 : 64 / CP;
@@ -1617,17 +1620,30 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // flush (and clear) the part of the tile the footprint box reaches
-        for (int ty = 0; ty < bh; ty++) {
-          const int gyy = oy + ty;
-          if ((unsigned)gyy >= (unsigned)a.H) continue;  // (nothing was added there)
-          float* trow = tile + ty * bw * CP;
-          float* grow = vbase + ((long long)gyy * a.W + ox) * CP;
-          for (int i = lane; i < bw * CP; i += 64) {
-            const float v = trow[i];
-            if (v != 0.0f) {
-              trow[i] = 0.0f;
-              unsafeAtomicAdd(grow + i, v);
+        // flush (and clear) the part of the tile the footprint box reaches: the box's rows
+        // follow each other in the tile, so it is swept as one run, four reads in flight
+        // (row by row every read was a round trip of its own: 27 instead of 5 per view)
+        {
+          const int rowlen = bw * CP, total = rowlen * bh;
+          const unsigned magic = 0xffffffffu / (unsigned)rowlen + 1u;  // f / rowlen, f < 2^16
+          constexpr int FU = 4;
+#pragma unroll 1
+          for (int f0 = 0; f0 < total; f0 += 64 * FU) {
+            float v[FU];
+#pragma unroll
+            for (int u = 0; u < FU; u++) {
+              const int f = f0 + 64 * u + lane;
+              v[u] = f < total ? tile[f] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < FU; u++) {
+              const int f = f0 + 64 * u + lane;
+              if (v[u] != 0.0f) {  // (texels outside the map were never added to)
+                tile[f] = 0.0f;
+                const int ty = (int)__umulhi((unsigned)f, magic);
+                const int rem = f - ty * rowlen;
+                unsafeAtomicAdd(vbase + ((long long)(oy + ty) * a.W + ox) * CP + rem, v[u]);
+              }
             }
           }
         }
