@@ -307,11 +307,10 @@ class WindowWorkload:
         self.P = P
         self.regular = self.groups is None and (T == 1 or P == 1)
         self.chunk = self.B
-        if T == 1 and self.groups is None and args.planes == 'off':  # (planes: one launch is faster)
+        whole = self.nhwc or args.planes != 'off'  # (planes: one launch unless asked otherwise)
+        if (T == 1 and self.groups is None) or (self.regular and not self.nhwc):
             self.chunk = min(self.B, args.window_chunk or
-                             (self.B if self.nhwc else ops.chunk_frames(self.V, h, w, cp)))
-        elif self.regular and args.planes == 'off' and not self.nhwc:
-            self.chunk = min(self.B, args.window_chunk or ops.chunk_frames(self.V, h, w, cp))
+                             (self.B if whole else ops.chunk_frames(self.V, h, w, cp)))
         self.hm = None if self.nhwc else torch.empty(self.chunk, self.V, h, w, cp, device=dev)
         # in-place layouts of every chunk's maps, built once (views of the callers' tensors)
         self.layouts = {f0: ops.channels_last_layout([f[f0:f0 + n] for f in self.fms])
