@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define TEMPO_ABI_VERSION 9
+#define TEMPO_ABI_VERSION 10
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
@@ -199,6 +199,17 @@ int tempo_unproject_root_views(const void* const* views, long long frame_bytes,
                                int H, int W, int X, int Y, int Z, float hm_w,
                                float hm_h, float img_w, float img_h, int mm_unfused,
                                void* stream);
+/* tempo_unproject_root_views that also returns the volume's maximum over z, as
+ * tempo_unproject_root_zmax does (center_net.py:230):
+ *   zmax : out fp32 [B, C, X, Y], bit-identical to torch.max(cubes, dim=4) */
+int tempo_unproject_root_views_zmax(const void* const* views, long long frame_bytes,
+                                    int texel_bytes, const float* cam, const float* ax_x,
+                                    const float* ax_y, const float* ax_z, int ax_batched,
+                                    const uint8_t* live, float* cubes, float* grids,
+                                    void* mask, int mask_bytes, int B, int V, int C, int CP,
+                                    int H, int W, int X, int Y, int Z, float hm_w,
+                                    float hm_h, float img_w, float img_h, int mm_unfused,
+                                    float* zmax, void* stream);
 int tempo_unproject_window_views(const void* const* views, long long frame_bytes,
                                  int texel_bytes, const float* cam,
                                  const int32_t* win_frame, const float* fx,

@@ -2743,6 +2743,23 @@ int tempo_unproject_root_views(const void* const* views, long long frame_bytes,
                    Extra(), stream);
 }
 
+int tempo_unproject_root_views_zmax(const void* const* views, long long frame_bytes,
+                                    int texel_bytes, const float* cam, const float* ax_x,
+                                    const float* ax_y, const float* ax_z, int ax_batched,
+                                    const uint8_t* live, float* cubes, float* grids, void* mask,
+                                    int mask_bytes, int B, int V, int C, int CP, int H, int W,
+                                    int X, int Y, int Z, float hm_w, float hm_h, float img_w,
+                                    float img_h, int mm_unfused, float* zmax, void* stream) {
+  if (!views || !zmax) return TEMPO_E_NULL;
+  Layout lay;
+  lay.views = views; lay.frame_bytes = frame_bytes; lay.texel_bytes = texel_bytes;
+  Extra ex;
+  ex.zmax = zmax;
+  return root_impl(lay, cam, ax_x, ax_y, ax_z, ax_batched, live, cubes, grids, mask, mask_bytes,
+                   B, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w, img_h, mm_unfused, nullptr, 0,
+                   ex, stream);
+}
+
 int tempo_unproject_window_views(const void* const* views, long long frame_bytes,
                                  int texel_bytes, const float* cam, const int32_t* win_frame,
                                  const float* fx, const float* fy, const float* fz,

@@ -709,8 +709,10 @@ def channels_last_layout(feature_maps, c_begin=0):
 
 
 def unproject_root_views(layout, cam, axes, channels, heatmap_size, image_size, live=None,
-                         want_grids=False, want_mask=False, out=None, mm_mode='auto'):
-    """:func:`unproject_root` on heatmaps in place (any :class:`MapLayout`)."""
+                         want_grids=False, want_mask=False, out=None, mm_mode='auto',
+                         zmax_out=None):
+    """:func:`unproject_root` on heatmaps in place (any :class:`MapLayout`); ``zmax_out``
+    ``[B,C,X,Y]`` also receives the volume's maximum over z (center_net.py:230)."""
     lib = _lib.load()
     dev = layout.device
     B, V, H, W = layout.F, layout.V, layout.H, layout.W
@@ -736,14 +738,21 @@ def unproject_root_views(layout, cam, axes, channels, heatmap_size, image_size, 
     if want_mask:
         mask_bytes, mdt = mask_dtype(V)
         mask = torch.empty(B, N, dtype=mdt, device=dev)
-    with torch.cuda.device(dev):
-        rc = lib.tempo_unproject_root_views(
-            layout.ptrs, layout.frame_bytes, layout.texel_bytes, _ptr(cam), _ptr(ax[0]),
+    head = (layout.ptrs, layout.frame_bytes, layout.texel_bytes, _ptr(cam), _ptr(ax[0]),
             _ptr(ax[1]), _ptr(ax[2]), int(batched), _ptr(live), _ptr(out), _ptr(grids),
             _ptr(mask), mask_bytes, B, V, C, CP, H, W, X, Y, Z, float(heatmap_size[0]),
             float(heatmap_size[1]), float(image_size[0]), float(image_size[1]),
-            numerics.abi_flag(mm_mode), _stream_ptr(dev))
-    _lib.check(rc, 'tempo_unproject_root_views')
+            numerics.abi_flag(mm_mode))
+    with torch.cuda.device(dev):
+        if zmax_out is None:
+            rc = lib.tempo_unproject_root_views(*head, _stream_ptr(dev))
+        else:
+            _need(zmax_out, torch.float32, 'zmax_out', dev)
+            if tuple(zmax_out.shape) != (B, C, X, Y):
+                raise ValueError(f'zmax_out must be [{B},{C},{X},{Y}]')
+            rc = lib.tempo_unproject_root_views_zmax(*head, _ptr(zmax_out), _stream_ptr(dev))
+    _lib.check(rc, 'tempo_unproject_root_views' if zmax_out is None
+               else 'tempo_unproject_root_views_zmax')
     return out, grids, mask
 
 

@@ -314,9 +314,8 @@ class ProjectLayer(nn.Module):
         cubes = torch.empty(B, C, *cube_size, dtype=torch.float32, device=device)
         grids = mask = None
         source = _map_source(feature_maps)
-        if source == 'packed' or (source == 'views' and not self.keep_zmax):
-            # maps already channel-last: read in place, no repack (frames in chunks of 8:
-            # one frame per XCD at a time)
+        if source in ('packed', 'views'):
+            # maps already channel-last: read in place, no repack
             self.last_zmax = None
             return self._get_voxel_in_place(feature_maps, source, cam, axes, live, cubes)
         zmax = (torch.empty(B, C, cube_size[0], cube_size[1], dtype=torch.float32,
@@ -353,7 +352,7 @@ class ProjectLayer(nn.Module):
         batched = axes[0].dim() == 2
         grids = mask = None
         zmax = None
-        if source == 'packed' and self.keep_zmax:
+        if self.keep_zmax:
             zmax = torch.empty(B, C, cubes.shape[2], cubes.shape[3], dtype=torch.float32,
                                device=cubes.device)
         chunk = B  # maps read where they lie: one launch over the batch is fastest
@@ -361,6 +360,8 @@ class ProjectLayer(nn.Module):
             first = c0 == 0
             out = cubes if cs == C else torch.empty(B, cs, *cubes.shape[2:], dtype=torch.float32,
                                                     device=cubes.device)
+            zs = None if zmax is None else (zmax if cs == C else torch.empty(
+                B, cs, *cubes.shape[2:4], dtype=torch.float32, device=cubes.device))
             gl, ml = [], []
             for b0 in range(0, B, chunk):
                 sl = slice(b0, min(B, b0 + chunk))
@@ -371,15 +372,18 @@ class ProjectLayer(nn.Module):
                 if source == 'packed':  # (at most 32 channels: one slice)
                     _, g, m = ops.unproject_root(
                         feature_maps.hm[sl], cam[sl], ax, cs, self.heatmap_size, self.image_size,
-                        zmax_out=None if zmax is None else zmax[sl], **kw)
+                        zmax_out=None if zs is None else zs[sl], **kw)
                 else:
                     lay = ops.channels_last_layout([fm[sl] for fm in feature_maps], c0)
-                    _, g, m = ops.unproject_root_views(lay, cam[sl], ax, cs, self.heatmap_size,
-                                                       self.image_size, **kw)
+                    _, g, m = ops.unproject_root_views(
+                        lay, cam[sl], ax, cs, self.heatmap_size, self.image_size,
+                        zmax_out=None if zs is None else zs[sl], **kw)
                 gl.append(g)
                 ml.append(m)
             if cs != C:
                 cubes[:, c0:c0 + cs] = out
+                if zs is not None:
+                    zmax[:, c0:c0 + cs] = zs
             if first:
                 grids = torch.cat(gl, 0) if gl[0] is not None else None
                 mask = torch.cat(ml, 0) if ml[0] is not None else None

@@ -142,7 +142,7 @@ def test_modules_take_channels_last_and_packed_maps(gpu_device):
     for name, maps in variants.items():
         layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
         layer.keep_mask = True
-        layer.keep_zmax = name != 'channels_last'
+        layer.keep_zmax = True  # (channel-last maps: tempo_unproject_root_views_zmax)
         with torch.no_grad():
             cubes, grids = layer(maps, *rest)
         outs[name] = (cubes, grids, layer.last_mask)
