@@ -297,8 +297,8 @@ class WindowWorkload:
         self.input_layout = args.input_layout
         self.nhwc = args.input_layout != 'nchw'
         if self.nhwc:
-            if self.groups is not None or args.planes != 'off':
-                raise SystemExit('--input-layout nhwc: plain window volumes only')
+            if self.groups is not None:
+                raise SystemExit('--input-layout nhwc: not with --share')
             pad = cp - self.J if args.input_layout == 'nhwc' else 0
             self.fms = [torch.nn.functional.pad(f, (0, 0, 0, 0, 0, pad)).contiguous(
                 memory_format=torch.channels_last) for f in self.fms]
@@ -359,6 +359,14 @@ class WindowWorkload:
         if self._memo is None:
             self._memo = {}
         ws, (tl, st, en), wf, cam = self._chunk_args(f0, n)
+        if self.nhwc and self.planes_mode != 'off':  # planes from maps read in place
+            self.ops.unproject_window_planes_views(
+                self.layouts[f0], cam, self.fine, tl, st, en, self.sub, self.J,
+                self.cfg['heatmap_size'], self.cfg['image_size'], win_frame=wf,
+                want_cubes=self.planes_mode == 'with',
+                out=None if self.out is None else self.out[ws],
+                planes_out=[p[ws] for p in self.planes])
+            return
         if self.nhwc:  # maps read in place
             self.ops.unproject_window_views(
                 self.layouts[f0], cam, self.fine, tl, st, en, self.sub, self.J,
@@ -733,8 +741,9 @@ def main():
         dist.all_reduce(one)
         seen = int(round(float(one.item())))
 
-    if args.input_layout != 'nchw' and (args.backward or args.planes != 'off' or args.share):
-        raise SystemExit('--input-layout nhwc times the forward volume kernels only')
+    if args.input_layout != 'nchw' and (args.backward or args.share or
+                                        (args.planes != 'off' and args.workload == 'root')):
+        raise SystemExit('--input-layout nhwc times the forward kernels only')
     wl = DryWorkload() if args.dry_run else make_workload(args, dev, seed=rank)
 
     for _ in range(args.warmup):
@@ -811,7 +820,7 @@ def main():
     # fused epilogue: what the reference's caller does instead (tempo_pose.py:172-176) --
     # the volume kernel followed by torch.max over each axis, on the same inputs
     unfused = None
-    if rank == 0 and getattr(wl, 'planes_mode', 'off') != 'off':
+    if rank == 0 and getattr(wl, 'planes_mode', 'off') != 'off' and not wl.nhwc:
         vol = wl.out if wl.out is not None else torch.empty(wl.NW, wl.J, *wl.sub, device=dev)
         tl, st, en = wl.geo
         wl.hm = torch.empty(wl.B, *wl.hm.shape[1:], device=dev)

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define TEMPO_ABI_VERSION 10
+#define TEMPO_ABI_VERSION 11
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
@@ -220,6 +220,22 @@ int tempo_unproject_window_views(const void* const* views, long long frame_bytes
                                  int FZ, int VX, int VY, int VZ, float hm_w,
                                  float hm_h, float img_w, float img_h, int mm_unfused,
                                  void* stream);
+/* tempo_unproject_window_planes on maps read in place (arguments as
+ * tempo_unproject_window_views + the planes of tempo_unproject_window_planes; cubes may be
+ * NULL): the pose regressor's three axis-max planes (tempo_pose.py:172-176) straight from
+ * channel-last maps, no repack and no volume. */
+int tempo_unproject_window_planes_views(const void* const* views, long long frame_bytes,
+                                        int texel_bytes, const float* cam,
+                                        const int32_t* win_frame, const float* fx,
+                                        const float* fy, const float* fz,
+                                        const int32_t* tl, const int32_t* start,
+                                        const int32_t* end, const uint8_t* live,
+                                        float* cubes, float* plane_xy, float* plane_xz,
+                                        float* plane_yz, int NW, int F, int V, int C,
+                                        int CP, int H, int W, int FX, int FY, int FZ,
+                                        int VX, int VY, int VZ, float hm_w, float hm_h,
+                                        float img_w, float img_h, int mm_unfused,
+                                        void* stream);
 
 /* tempo_unproject_root for a batch in which runs of consecutive items share one
  * calibration and one grid -- the frames of one recording; the reference

@@ -2776,6 +2776,26 @@ int tempo_unproject_window_views(const void* const* views, long long frame_bytes
                      img_w, img_h, mm_unfused, nullptr, 0, Extra(), stream);
 }
 
+int tempo_unproject_window_planes_views(const void* const* views, long long frame_bytes,
+                                        int texel_bytes, const float* cam,
+                                        const int32_t* win_frame, const float* fx,
+                                        const float* fy, const float* fz, const int32_t* tl,
+                                        const int32_t* start, const int32_t* end,
+                                        const uint8_t* live, float* cubes, float* plane_xy,
+                                        float* plane_xz, float* plane_yz, int NW, int F, int V,
+                                        int C, int CP, int H, int W, int FX, int FY, int FZ,
+                                        int VX, int VY, int VZ, float hm_w, float hm_h,
+                                        float img_w, float img_h, int mm_unfused,
+                                        void* stream) {
+  if (!views) return TEMPO_E_NULL;
+  if (!cubes && !plane_xy && !plane_xz && !plane_yz) return TEMPO_E_NULL;
+  Layout lay;
+  lay.views = views; lay.frame_bytes = frame_bytes; lay.texel_bytes = texel_bytes;
+  return window_impl(lay, cam, win_frame, fx, fy, fz, tl, start, end, live, cubes, plane_xy,
+                     plane_xz, plane_yz, NW, F, V, C, CP, H, W, FX, FY, FZ, VX, VY, VZ, hm_w,
+                     hm_h, img_w, img_h, mm_unfused, nullptr, 0, Extra(), stream);
+}
+
 int tempo_unproject_window(const float* hm, const float* cam, const int32_t* win_frame,
                            const float* fx, const float* fy, const float* fz,
                            const int32_t* tl, const int32_t* start, const int32_t* end,

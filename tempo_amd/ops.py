@@ -799,6 +799,65 @@ def unproject_window_views(layout, cam, fine_axes, tl, start, end, sub_cube, cha
     return out
 
 
+def unproject_window_planes_views(layout, cam, fine_axes, tl, start, end, sub_cube, channels,
+                                  heatmap_size, image_size, win_frame=None, live=None,
+                                  want_cubes=False, mm_mode='auto', out=None, planes_out=None):
+    """:func:`unproject_window_planes` on heatmaps in place (any :class:`MapLayout`): the
+    three axis-max planes without a repack and, with ``want_cubes=False``, without the
+    volume.  Returns ``(cubes | None, plane_xy, plane_xz, plane_yz)``."""
+    lib = _lib.load()
+    dev = layout.device
+    F_, V, H, W = layout.F, layout.V, layout.H, layout.W
+    _need(cam, torch.float32, 'cam', dev)
+    if tuple(cam.shape) != (F_, V, 32):
+        raise ValueError(f'cam must be [{F_},{V},32], got {tuple(cam.shape)}')
+    fa = [_need(a, torch.float32, 'fine_axes', dev) for a in fine_axes]
+    NW = int(tl.shape[0])
+    for name, t in (('tl', tl), ('start', start), ('end', end)):
+        _need(t, torch.int32, name, dev)
+        if tuple(t.shape) != (NW, 3):
+            raise ValueError(f'{name} must be [{NW},3]')
+    if win_frame is not None:
+        _need(win_frame, torch.int32, 'win_frame', dev)
+        if win_frame.numel() != NW:
+            raise ValueError('win_frame must have one entry per window')
+    elif NW != F_:
+        raise ValueError('without win_frame there must be one window per frame')
+    if live is not None:
+        _need(live, torch.uint8, 'live', dev)
+        if live.numel() != NW:
+            raise ValueError('live must have one entry per window')
+    VX, VY, VZ = (int(v) for v in sub_cube)
+    C = int(channels)
+    CP = padded_channels(C)
+    cubes = None
+    if want_cubes:
+        cubes = out if out is not None else torch.empty(NW, C, VX, VY, VZ,
+                                                        dtype=torch.float32, device=dev)
+        _need(cubes, torch.float32, 'out', dev)
+        if cubes.numel() != NW * C * VX * VY * VZ:
+            raise ValueError('out has the wrong size')
+    shapes = [(NW, C, VX, VY), (NW, C, VX, VZ), (NW, C, VY, VZ)]
+    if planes_out is None:
+        planes = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
+    else:
+        planes = list(planes_out)
+        for t, sh in zip(planes, shapes):
+            _need(t, torch.float32, 'planes_out', dev)
+            if tuple(t.shape) != sh:
+                raise ValueError(f'planes_out: expected {sh}, got {tuple(t.shape)}')
+    with torch.cuda.device(dev):
+        rc = lib.tempo_unproject_window_planes_views(
+            layout.ptrs, layout.frame_bytes, layout.texel_bytes, _ptr(cam), _ptr(win_frame),
+            _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]), _ptr(tl), _ptr(start), _ptr(end), _ptr(live),
+            _ptr(cubes), _ptr(planes[0]), _ptr(planes[1]), _ptr(planes[2]), NW, F_, V, C, CP,
+            H, W, int(fa[0].numel()), int(fa[1].numel()), int(fa[2].numel()), VX, VY, VZ,
+            float(heatmap_size[0]), float(heatmap_size[1]), float(image_size[0]),
+            float(image_size[1]), numerics.abi_flag(mm_mode), _stream_ptr(dev))
+    _lib.check(rc, 'tempo_unproject_window_planes_views')
+    return cubes, planes[0], planes[1], planes[2]
+
+
 def gather_zcolumns(cubes, index, out=None):
     """``cubes [B,C,X,Y,Z]``, ``index`` int64 ``[B,K]`` (cell = x * Y + y) ->
     ``[B,K,C,Z]``: the z-columns the root detector's 1-D stage reads

@@ -621,14 +621,20 @@ class ProjectLayerWithMask(nn.Module):
                  if want_cubes else None)
         planes = [torch.empty(B, C, *sh, dtype=torch.float32, device=device)
                   for sh in ((vx, vy), (vx, vz), (vy, vz))]
+        source = _map_source(feature_maps)
         for c0, cs in _Slices(C).items:
-            hm = ops.repack_nhwc(feature_maps, c0, cs)
             whole = cs == C
-            out = ops.unproject_window_planes(
-                hm, cam, self._fine_axes, tl, st, en, self._sub_cube, cs,
-                self.heatmap_size, self.image_size, live=live, want_cubes=want_cubes,
-                mm_mode=self.mm_mode, out=cubes if whole else None,
-                planes_out=planes if whole else None)
+            kw = dict(live=live, want_cubes=want_cubes, mm_mode=self.mm_mode,
+                      out=cubes if whole else None, planes_out=planes if whole else None)
+            if source == 'views':  # channels_last tensors read in place: no repack
+                out = ops.unproject_window_planes_views(
+                    ops.channels_last_layout(list(feature_maps), c0), cam, self._fine_axes, tl,
+                    st, en, self._sub_cube, cs, self.heatmap_size, self.image_size, **kw)
+            else:  # (packed maps hold at most 32 channels: one slice)
+                hm = feature_maps.hm if source == 'packed' else ops.repack_nhwc(feature_maps, c0, cs)
+                out = ops.unproject_window_planes(
+                    hm, cam, self._fine_axes, tl, st, en, self._sub_cube, cs,
+                    self.heatmap_size, self.image_size, **kw)
             if not whole:
                 if want_cubes:
                     cubes[:, c0:c0 + cs] = out[0]

@@ -258,3 +258,37 @@ def test_window_geometry_kernel_equals_the_tensor_ops(cols, gpu_device):
     assert torch.equal(en.to(torch.int32), en2)
     assert torch.equal(off.view(torch.int32), off2.view(torch.int32))
     assert torch.equal((gc[:, 3] >= 0).to(torch.uint8), live2)
+
+
+@pytest.mark.parametrize('want_cubes', [False, True])
+def test_window_planes_on_maps_in_place(want_cubes, gpu_device):
+    """tempo_unproject_window_planes_views: the pose regressor's axis-max planes
+    (tempo_pose.py:172-176) from channels_last tensors and from PackedHeatmaps, no repack,
+    bit-identical to the NCHW path and to torch.max over the HIP volume."""
+    import cases
+    import tempo_amd
+    from tempo_amd import ops
+    case = cases.to_device(cases.build_window('win_panoptic_small'), gpu_device)
+    fms, gc = case['args'][0], case['args'][1]
+    rest = case['args'][6:]
+    variants = {
+        'nchw': fms,
+        'channels_last': [f.contiguous(memory_format=torch.channels_last) for f in fms],
+        'packed': tempo_amd.PackedHeatmaps(ops.repack_nhwc(fms), fms[0].shape[1]),
+    }
+    outs = {}
+    for name, maps in variants.items():
+        layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+        with torch.no_grad():
+            cubes, _ = layer(maps, *case['args'][1:])
+            outs[name] = layer.get_planes(maps, gc, *rest, want_cubes=want_cubes)
+        torch.cuda.synchronize()
+        pxy, pxz, pyz, _, cubes2 = outs[name]
+        assert (cubes2 is not None) == want_cubes
+        if want_cubes:
+            assert torch.equal(_canon(cubes), _canon(cubes2))
+        for got, dim in ((pxy, 4), (pxz, 3), (pyz, 2)):
+            assert torch.equal(_canon(got), _canon(cubes.max(dim=dim)[0])), (name, dim)
+    for name in ('channels_last', 'packed'):
+        for a, b in zip(outs[name][:3], outs['nchw'][:3]):
+            assert torch.equal(_canon(a), _canon(b)), name
