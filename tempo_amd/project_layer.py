@@ -83,6 +83,22 @@ class ProcessLayerNHWC(nn.Module):
         return [PackedHeatmaps(hm[t * B:(t + 1) * B], C) for t in range(timesteps)]
 
 
+def _packed_sequence(feature_maps_t):
+    """``[T*B,V,H,W,CP]`` view when the timesteps are :class:`PackedHeatmaps` that follow
+    each other in one buffer (what :class:`ProcessLayerNHWC` returns), else None."""
+    if not all(isinstance(f, PackedHeatmaps) for f in feature_maps_t):
+        return None
+    first = feature_maps_t[0].hm
+    step = first.numel() * first.element_size()
+    for t, f in enumerate(feature_maps_t):
+        if (f.hm.shape != first.shape or f.channels != feature_maps_t[0].channels or
+                f.hm.untyped_storage().data_ptr() != first.untyped_storage().data_ptr() or
+                f.hm.data_ptr() != first.data_ptr() + t * step):
+            return None
+    T = len(feature_maps_t)
+    return torch.as_strided(first, (T * first.shape[0],) + tuple(first.shape[1:]), first.stride())
+
+
 def _map_source(feature_maps):
     """How the forward kernels get at the maps: ('packed', PackedHeatmaps),
     ('views', list of channels_last tensors read in place) or ('nchw', list to repack)."""
@@ -347,12 +363,14 @@ class ProjectLayer(nn.Module):
         self.last_zmax = zmax
         return cubes, grids
 
-    def _get_voxel_in_place(self, feature_maps, source, cam, axes, live, cubes):
+    def _get_voxel_in_place(self, feature_maps, source, cam, axes, live, cubes, plain=False):
+        """Maps read where they lie; ``plain``: the volume only (no grids, mask, z-max; the
+        module's ``last_*`` attributes are left alone)."""
         B, C = cubes.shape[:2]
         batched = axes[0].dim() == 2
         grids = mask = None
         zmax = None
-        if self.keep_zmax:
+        if self.keep_zmax and not plain:
             zmax = torch.empty(B, C, cubes.shape[2], cubes.shape[3], dtype=torch.float32,
                                device=cubes.device)
         chunk = B  # maps read where they lie: one launch over the batch is fastest
@@ -367,8 +385,9 @@ class ProjectLayer(nn.Module):
                 sl = slice(b0, min(B, b0 + chunk))
                 ax = [a[sl] for a in axes] if batched else axes
                 lv = None if live is None else live[sl]
-                kw = dict(live=lv, want_grids=first and self.materialize_grids,
-                          want_mask=first and self.keep_mask, out=out[sl], mm_mode=self.mm_mode)
+                kw = dict(live=lv, want_grids=first and self.materialize_grids and not plain,
+                          want_mask=first and self.keep_mask and not plain, out=out[sl],
+                          mm_mode=self.mm_mode)
                 if source == 'packed':  # (at most 32 channels: one slice)
                     _, g, m = ops.unproject_root(
                         feature_maps.hm[sl], cam[sl], ax, cs, self.heatmap_size, self.image_size,
@@ -387,6 +406,8 @@ class ProjectLayer(nn.Module):
             if first:
                 grids = torch.cat(gl, 0) if gl[0] is not None else None
                 mask = torch.cat(ml, 0) if ml[0] is not None else None
+        if plain:
+            return cubes, None
         self.last_mask = mask
         self.last_zmax = zmax
         return cubes, grids
@@ -424,8 +445,16 @@ class ProjectLayer(nn.Module):
         # one library call per timestep: its chunk loop keeps a chunk's channel-last maps
         # cached between the repack and the gather (one launch over all T*B frames reads
         # them back from HBM: 0.34 against 0.27 ms per 32 frames at config 2)
+        for t in range(T):  # timesteps whose maps are already channel-last: in place
+            source = _map_source(feature_maps_t[t])
+            if source != 'nchw':
+                sl = slice(t * B, (t + 1) * B)
+                self._get_voxel_in_place(feature_maps_t[t], source, cam[sl],
+                                         [a[sl] for a in axes], live[sl], cubes[sl], plain=True)
         for c0, n in _Slices(C).items:
             for t in range(T):
+                if _map_source(feature_maps_t[t]) != 'nchw':
+                    continue
                 sl = slice(t * B, (t + 1) * B)
                 out, _, _ = ops.root_step(
                     feature_maps_t[t], cam[sl], [a[sl] for a in axes], self.heatmap_size,
@@ -684,11 +713,19 @@ class ProjectLayerWithMask(nn.Module):
                  if want_cubes else None)
         planes = [torch.empty(NW, C, *sh, dtype=torch.float32, device=device)
                   for sh in ((vx, vy), (vx, vz), (vy, vz))]
+        packed_all = _packed_sequence(feature_maps_t)
         for c0, n in _Slices(C).items:
             cp = ops.padded_channels(n)
-            hm = torch.empty(T * B, V, H, W, cp, dtype=torch.float32, device=device)
-            for t in range(T):
-                ops.repack_nhwc(feature_maps_t[t], c0, n, out=hm[t * B:(t + 1) * B])
+            if packed_all is not None:  # one buffer, frames ordered (t, b): no repack
+                hm = packed_all
+            else:
+                hm = torch.empty(T * B, V, H, W, cp, dtype=torch.float32, device=device)
+                for t in range(T):
+                    fm_t = feature_maps_t[t]
+                    if isinstance(fm_t, PackedHeatmaps):
+                        hm[t * B:(t + 1) * B] = fm_t.hm
+                    else:
+                        ops.repack_nhwc(fm_t, c0, n, out=hm[t * B:(t + 1) * B])
             whole = n == C
             out = ops.unproject_window_planes(
                 hm, cam, self._fine_axes, tl, st, en, self._sub_cube, n, self.heatmap_size,

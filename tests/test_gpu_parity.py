@@ -280,6 +280,17 @@ def test_root_forward_sequence_equals_loop(gpu_device):
                                      [d['args'][6] for d in ds])
     canon = lambda t: torch.nan_to_num(t, nan=-1.0)
     assert seq.shape == loop.shape and torch.equal(canon(seq), canon(loop))
+    # timesteps already channel-last (packed by the producer / channels_last tensors) are read
+    # in place, NCHW ones repacked: same volume
+    from tempo_amd import ops
+    mixed = [tempo_amd.PackedHeatmaps(ops.repack_nhwc(ds[0]['args'][0]), ds[0]['args'][0][0].shape[1]),
+             [f.contiguous(memory_format=torch.channels_last) for f in ds[1]['args'][0]],
+             ds[2]['args'][0]]
+    with torch.no_grad():
+        seq2 = layer.forward_sequence(mixed, ds[0]['args'][1], [d['args'][2] for d in ds],
+                                      ds[0]['args'][3], [d['args'][4] for d in ds],
+                                      [d['args'][5] for d in ds], [d['args'][6] for d in ds])
+    assert torch.equal(canon(seq2), canon(seq))
     # and against the oracle's own loop over time_idx (tempo_detector.py:175-191)
     ref_layer = O.ProjectLayer(cs[0]['image_size'], cs[0]['heatmap_size'], 'mean')
     ref = torch.cat([ref_layer(*c['args'])[0] for c in cs], dim=0)
@@ -371,6 +382,27 @@ def test_window_forward_sequence_planes_equals_loops(gpu_device):
                 assert torch.equal(pxy[:, n, t], ref.max(dim=4)[0])
                 assert torch.equal(pxz[:, n, t], ref.max(dim=3)[0])
                 assert torch.equal(pyz[:, n, t], ref.max(dim=2)[0])
+    # the producer's output -- one channel-last buffer, frames ordered (t, b), handed over as
+    # one PackedHeatmaps per timestep -- is used where it lies
+    from tempo_amd import ops
+    from tempo_amd.project_layer import _packed_sequence
+    J = cfg['num_joints']
+    buf = torch.cat([ops.repack_nhwc(fms_t[t]) for t in range(T)], 0)
+    packed_t = [tempo_amd.PackedHeatmaps(buf[t * B:(t + 1) * B], J) for t in range(T)]
+    assert _packed_sequence(packed_t) is not None
+    assert _packed_sequence(packed_t[::-1]) is None
+    with torch.no_grad():
+        got = layer.forward_sequence_planes(
+            packed_t, cand, cfg['space_center'], space, sub, sub_cube, [centers] * T,
+            [scales] * T, [cameras] * T, want_cubes=True)
+        got_rev = layer.forward_sequence_planes(  # (not one buffer in order: copied)
+            [tempo_amd.PackedHeatmaps(p.hm.clone(), J) for p in packed_t], cand,
+            cfg['space_center'], space, sub, sub_cube, [centers] * T, [scales] * T,
+            [cameras] * T, want_cubes=False)
+    for a, b in zip(got, (pxy, pxz, pyz, off, cubes)):
+        assert torch.equal(a, b)
+    for a, b in zip(got_rev[:4], (pxy, pxz, pyz, off)):
+        assert torch.equal(a, b)
     # and against the oracle's loops over candidates and time_idx (tempo_pose.py:145-176,
     # :266): cubes, offset and the three axis-max planes
     ref_layer = O.ProjectLayerWithMask(cfg['image_size'], cfg['heatmap_size'], 'mean')
