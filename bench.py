@@ -224,7 +224,7 @@ class RootWorkload:
         """(kernel ms, repack ms) per step and kernel launches per step: HIP events around
         every launch, on the launch stream, enqueued behind a blocker so that no interval
         contains host launch latency."""
-        steps = min(steps, 10)
+        steps = min(max(steps, 10), 30)
         E = lambda: torch.cuda.Event(enable_timing=True)
         ks, rs = [], []
         for c0, n in self._chunks():  # (first use of these entry points: not timed)
