@@ -530,6 +530,27 @@ def test_root_zmax_equals_torch_max(name, gpu_device):
     assert torch.equal(canon(layer.last_zmax), canon(cubes.max(dim=4)[0]))
 
 
+@pytest.mark.parametrize('z', [5, 24, 27, 64, 70])
+def test_root_zmax_column_shapes(z, gpu_device):
+    """The z-max's three code paths: waves of whole columns (z = 5: 60 of 64 lanes), columns
+    that straddle waves with too many idle lanes otherwise (24, 27: segmented maximum + one
+    atomic per segment), columns of a whole wave and longer (64, 70)."""
+    import tempo_amd
+    spec = dict(cases.ROOT_CASES['root_panoptic_noise'], cube=[6, 5, z], B=2, seed=400 + z)
+    case = cases.to_device(cases.build_root('root_panoptic_noise', full=spec), gpu_device)
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    layer.keep_zmax = True
+    with torch.no_grad():
+        cubes, _ = layer(*case['args'])
+    canon = lambda t: torch.nan_to_num(t, nan=-1.0)
+    assert cubes.shape[-1] == z
+    assert torch.equal(canon(layer.last_zmax), canon(cubes.max(dim=4)[0]))
+    plain = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    with torch.no_grad():
+        ref, _ = plain(*case['args'])
+    assert torch.equal(canon(cubes), canon(ref))  # (the wave shape does not change the volume)
+
+
 @pytest.mark.parametrize('variant', ['root', 'window'])
 def test_extreme_heatmap_values_bit_exact(variant, gpu_device):
     """Channels scaled into the fp32 denormal range and up to the overflow threshold, a NaN
