@@ -89,3 +89,45 @@ def test_static_scratch_rejects_what_does_not_fit(gpu_device):
     assert lib.tempo_root_step_static(ptrs, 15, 0, one, one, one, one, 0, None, one, None, None,
                                       0, 1, 8, 15, 16, 64, 64, 8, 8, 8, 64.0, 64.0, 64.0, 64.0,
                                       0, 0, None) == -2  # chunk <= 0
+
+
+def test_static_scratch_entry_under_graph_capture(gpu_device):
+    """The callers the entry point exists for: captured into a HIP graph (where hipMalloc is
+    not allowed) and replayed on new maps written into the same tensors."""
+    from tempo_amd import _lib, numerics, ops
+    lib = _lib.load()
+    dev = gpu_device
+    B, V, J, H, W, cube, chunk = 5, 5, 15, 64, 96, [12, 10, 9], 2
+    cfg, fms, cam, axes = _inputs(dev, B, V, J, H, W, cube, 311)
+    cfg = dict(cfg, heatmap_size=[W, H])
+    # eager first: the array's device address is looked up at the first call on a device
+    ref1 = _call('tempo_root_step_static', dev, cfg, fms, cam, axes, J, cube, chunk)[0]
+    cp = ops.padded_channels(J)
+    X, Y, Z = cube
+    out = torch.zeros(B, J, X, Y, Z, device=dev)
+    ptrs = (ctypes.c_void_p * V)(*[f.data_ptr() for f in fms])
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            rc = lib.tempo_root_step_static(
+                ptrs, J, 0, P(cam), P(axes[0]), P(axes[1]), P(axes[2]), 0, None, P(out), None,
+                None, 0, B, V, J, cp, H, W, X, Y, Z, float(W), float(H),
+                float(cfg['image_size'][0]), float(cfg['image_size'][1]),
+                numerics.abi_flag('auto'), chunk,
+                ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    assert rc == 0, lib.tempo_error_string(rc)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    canon = lambda t: torch.nan_to_num(t, nan=-1.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(canon(out), canon(ref1))
+    for f in fms:  # new maps in the captured tensors
+        f.mul_(0.5).add_(0.25)
+    ref2 = _call('tempo_root_step_static', dev, cfg, fms, cam, axes, J, cube, chunk)[0]
+    out.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(canon(out), canon(ref2)) and not torch.equal(canon(ref1), canon(ref2))
