@@ -135,3 +135,27 @@ def test_window_geometry_rejects_bad_arguments():
         kw.get('FX', 253), 253, 64, 64, 64, 64, kw.get('tl', one), one, one, one, None, None)
     assert geo(gc=None) == -1 and geo(tl=None) == -1
     assert geo(B=0) == -2 and geo(cols=5) == -2 and geo(FX=1) == -2
+
+
+def test_fused_consumer_entry_points_reject_bad_arguments():
+    """tempo_root_step_zmax, tempo_unproject_root_views_zmax and
+    tempo_unproject_window_planes_views: missing outputs / inputs are refused before anything
+    touches the GPU."""
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    one = P(16)
+    ptrs = (ctypes.c_void_p * 5)(*([16] * 5))
+    step = lambda zmax, ws=one: lib.tempo_root_step_zmax(
+        ptrs, 15, 0, one, one, one, one, 0, None, one, None, None, 0, 2, 5, 15, 16, 8, 8, 4, 4, 4,
+        8.0, 8.0, 32.0, 32.0, 0, zmax, ws, 2, None)
+    assert step(None) == -1           # no z-max plane: use tempo_root_step
+    assert step(one, ws=None) == -1   # no workspace
+    views = lambda zmax, v=ptrs: lib.tempo_unproject_root_views_zmax(
+        v, 8 * 8 * 64, 64, one, one, one, one, 0, None, one, None, None, 0, 2, 5, 15, 16, 8, 8,
+        4, 4, 4, 8.0, 8.0, 32.0, 32.0, 0, zmax, None)
+    assert views(None) == -1 and views(one, v=None) == -1
+    planes = lambda v=ptrs, cubes=None, pxy=one: lib.tempo_unproject_window_planes_views(
+        v, 8 * 8 * 64, 64, one, None, one, one, one, one, one, one, None, cubes, pxy, pxy, pxy,
+        2, 2, 5, 15, 16, 8, 8, 9, 9, 9, 4, 4, 4, 8.0, 8.0, 32.0, 32.0, 0, None)
+    assert planes(v=None) == -1
+    assert planes(pxy=None) == -1     # neither the volume nor a plane asked for
