@@ -2087,8 +2087,8 @@ int launch_one(const UnprojArgs& a, hipStream_t stream) {
   }
   // root z-max (the only plane asked for): waves of whole z-columns, so that every column's
   // maximum is complete inside one wave and is stored instead of max-accumulated with
-  // atomics (config 2: 60 of 64 lanes busy; the fused z-max then costs +0.01 instead of
-  // +0.06 ms per step)
+  // atomics (config 2: 60 of 64 lanes busy; the fused z-max then costs +0.03 instead of
+  // +0.07 ms per step)
   if (MODE == MODE_ROOT && a.pl01 != nullptr && a.pl02 == nullptr && a.pl12 == nullptr &&
       a.cmask == nullptr)
     k.wave_vox = zmax_wave_vox(a.dim[2]);
