@@ -62,6 +62,16 @@ def parse(argv=None):
     ap.add_argument('--planes', default='off', choices=['off', 'with', 'only'],
                     help='window workloads: fused axis-max planes (tempo_pose.py:172-176) '
                          'next to the volume, or instead of it')
+    ap.add_argument('--zmax', default='off', choices=['off', 'with', 'only'],
+                    help='root workload: the detector\'s consumers fused in -- the z-max planes '
+                         '(center_net.py:230) next to the volume, or `only`: z-max planes with '
+                         'cubes = NULL plus the K z-columns (tempo_detector.py:204-206) computed '
+                         'from the heatmaps, so that the volume is never written')
+    ap.add_argument('--columns', type=int, default=10,
+                    help='--zmax only: z-columns per frame (the detector\'s top-K cells)')
+    ap.add_argument('--min-seconds', type=float, default=1.5,
+                    help='the number of timed blocks is raised until the timed region lasts at '
+                         'least this long (steps per block stay as given)')
     ap.add_argument('--backward', action='store_true',
                     help='also time the training step (forward with clamp mask + backward + '
                          'un-repack) and report it beside the headline')
@@ -175,11 +185,30 @@ class RootWorkload:
         self.hm = None if self.nhwc else torch.empty(self.chunk, self.V, h, w, cp, device=dev)
         self.layouts = {c0: ops.channels_last_layout([f[c0:c0 + n] for f in self.fms])
                         for c0, n in self._chunks()} if self.nhwc else None
-        self.out = torch.empty(self.B, self.J, X, Y, Z, device=dev)
+        self.zmax_mode = getattr(args, 'zmax', 'off')
+        if self.zmax_mode != 'off' and (self.groups is not None or self.nhwc):
+            raise SystemExit('--zmax times the repacked root step')
+        self.out = (torch.empty(self.B, self.J, X, Y, Z, device=dev)
+                    if self.zmax_mode != 'only' else None)
+        self.zmax = (torch.empty(self.B, self.J, X, Y, device=dev)
+                     if self.zmax_mode != 'off' else None)
+        self.K = args.columns if self.zmax_mode == 'only' else 0
+        if self.K:
+            g = torch.Generator().manual_seed(seed + 5)
+            self.col_index = torch.randint(0, X * Y, (self.B, self.K), generator=g).to(dev)
+            self.cols = torch.empty(self.B, self.K, self.J, Z, device=dev)
         self.samples = self.B * self.N * self.V
-        # volume written once + every heatmap element read once + cameras
-        self.kernel_bytes = (4 * self.B * self.J * self.N + 4 * self.B * self.V * self.J * h * w
+        # outputs written once + every heatmap element read once + cameras
+        # (--zmax only: the outputs are the z-max planes and the K z-columns, no volume)
+        out_elems = ((self.B * self.J * self.N if self.zmax_mode != 'only' else 0) +
+                     (self.B * self.J * X * Y if self.zmax_mode != 'off' else 0) +
+                     self.B * self.K * self.J * Z)
+        self.kernel_bytes = (4 * out_elems + 4 * self.B * self.V * self.J * h * w
                              + 128 * self.B * self.V)
+        if self.zmax_mode == 'only':
+            self.name += '_zmax_columns_no_volume'
+        elif self.zmax_mode == 'with':
+            self.name += '_with_zmax'
         self.kernel_name = ('unproject_group_kernel<ROOT>' if self.groups is not None
                             else 'unproject_kernel<ROOT>')
 
@@ -202,7 +231,16 @@ class RootWorkload:
         else:
             self.ops.unproject_root(self.hm[:n], self.cam[c0:c0 + n], self.axes, self.J,
                                     cfg['heatmap_size'], cfg['image_size'],
-                                    out=self.out[c0:c0 + n], groups=self.groups)
+                                    out=None if self.out is None else self.out[c0:c0 + n],
+                                    groups=self.groups,
+                                    zmax_out=None if self.zmax is None else self.zmax[c0:c0 + n],
+                                    want_cubes=self.out is not None)
+
+    def columns(self):
+        """the K z-columns per frame straight from the NCHW maps (tempo_root_step_columns)"""
+        cfg = self.cfg
+        self.ops.unproject_root_columns(self.fms, self.cam, self.axes, self.col_index,
+                                        cfg['heatmap_size'], cfg['image_size'], out=self.cols)
 
     def step(self):
         cfg = self.cfg
@@ -218,7 +256,10 @@ class RootWorkload:
         # chunk, one reused channel-last workspace)
         self.ops.root_step(self.fms, self.cam, self.axes, cfg['heatmap_size'],
                            cfg['image_size'], out=self.out, chunk=self.chunk,
-                           hm_buf=self.hm.view(-1))
+                           hm_buf=self.hm.view(-1), zmax_out=self.zmax,
+                           want_cubes=self.out is not None)
+        if self.K:
+            self.columns()
 
     def parts(self, steps):
         """(kernel ms, repack ms) per step and kernel launches per step: HIP events around
@@ -456,8 +497,8 @@ class DenseWorkload:
     def step(self):
         self.repack()
         self.kernel()
-        if self.world > 1:
-            self.full = self.parallel.gather_z_slabs(self.out)
+        # the collective is part of the step at any rank count (one rank: a one-rank group)
+        self.full = self.parallel.gather_z_slabs(self.out)
 
 
 def make_workload(args, dev, seed):
@@ -515,6 +556,7 @@ def cpu_baseline(args):
                 if backward:
                     cubes.sum().backward()
             torch.cuda.synchronize()
+            return cubes
 
         for backward in (False, True):
             for _ in range(3):
@@ -529,6 +571,7 @@ def cpu_baseline(args):
         gpu['fwd_gsamp_s'] = round(n * V / (gpu['fwd_ms'] * 1e-3) / 1e9, 4)
         gpu['what'] = ('oracle ProjectLayer (reference-structured torch ops) with tensors on '
                        'this GPU, same 640000-sample call, median of 10, host-synchronised')
+        cpu_baseline.on_gpu_check = oracle_on_gpu_check(layer, cfg, dev, centers, scales, cameras)
     return {
         'torch_ops_on_gpu': gpu,
         'value': round(n * V / med / 1e9, 6), 'unit': 'Gsamp/s', 'cores': cores,
@@ -539,6 +582,38 @@ def cpu_baseline(args):
         'sample_1_thread': f'same call, torch.set_num_threads(1), median of {calls1} calls, '
                            f'{med1 * 1e3:.1f} ms/call',
     }
+
+
+def oracle_on_gpu_check(ref_layer, cfg, dev, centers, scales, cameras):
+    """How far the HIP path is from the reference's torch ops EXECUTED ON THIS GPU (report
+    only: the bar of the parity tests is torch on the CPU; ATen's GPU kernels round the K=3
+    matmuls, grid_sample and the view sum their own way).  Same frame through the oracle with
+    device tensors and through the drop-in module; blob and noise maps."""
+    import tempo_amd
+    from tempo_amd import synthetic as S
+    V, J = cfg['num_views'], cfg['num_joints']
+    w, h = cfg['heatmap_size']
+    mine = tempo_amd.ProjectLayer(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    mine.keep_mask = True
+    mine.materialize_grids = False
+    res = {'what': 'HIP module vs oracle ProjectLayer run with tensors on this GPU (ATen GPU '
+                   'kernels), config 1 frame; report only -- the parity bar is torch on the CPU'}
+    for kind in ('blobs', 'noise'):
+        fms = [f.to(dev) for f in S.make_heatmaps(1, V, J, h, w, kind=kind, seed=0)]
+        with torch.no_grad():
+            ref, _ = ref_layer(fms, cfg['space_size'], [cfg['space_center']], cfg['cube_size'],
+                               centers, scales, cameras)
+            got, _ = mine(fms, cfg['space_size'], [cfg['space_center']], cfg['cube_size'],
+                          centers, scales, cameras)
+        bits = (ref_layer.last_bounding.to(torch.int32) <<
+                torch.arange(V, dtype=torch.int32, device=ref_layer.last_bounding.device)).sum(-1)
+        mask_diff = int((bits.view(-1).to(dev) != mine.last_mask.view(-1).to(torch.int32)).sum())
+        d = (torch.nan_to_num(got) - torch.nan_to_num(ref)).abs()
+        res[kind] = {'max_abs': float(d.max()),
+                     'differing_elements': int((d != 0).sum()), 'elements': d.numel(),
+                     'nan_positions_equal': bool(torch.equal(got.isnan(), ref.isnan())),
+                     'differing_mask_words': mask_diff, 'mask_words': bits.numel()}
+    return res
 
 
 def measured_traffic(args, wl):
@@ -554,18 +629,26 @@ def measured_traffic(args, wl):
             or args.planes == 'with' or args.share):
         return None, None
     tag = 'root' if args.workload == 'root' else ('planes' if args.planes == 'only' else 'window')
+    zmode = getattr(args, 'zmax', 'off')
+    if zmode == 'with' or (zmode == 'only' and args.columns != 10):
+        return None, None
+    if zmode == 'only':
+        tag = 'root_zmax_only'
+    if args.channels == 32:
+        tag += '_c32'
     layout = getattr(wl, 'input_layout', 'nchw')
     if layout == 'nhwc':
         tag += '_nhwc'
     here = os.path.dirname(os.path.abspath(__file__))
     path = src = None
-    for rnd in ('r02', 'r01'):  # the newest committed profile of this configuration
+    for rnd in ('r03', 'r02', 'r01'):  # the newest committed profile of this configuration
         cand = os.path.join(here, 'profiles', rnd, tag + '_pmc_summary.csv')
         if os.path.exists(cand):
             path, src = cand, f'profiles/{rnd}/{tag}_pmc_summary.csv'
             break
     if (path is None or layout == 'nhwc-tight' or args.batch != 32 or args.chunk is not None
-            or (not tag.startswith('root') and args.proposals != 10) or args.channels):
+            or (not tag.startswith('root') and args.proposals != 10)
+            or (args.channels and args.channels != 32)):
         return None, None
     vals = {}
     with open(path) as f:
@@ -641,8 +724,18 @@ def oracle_check(args, wl, dev):
             return None
         layer = O.ProjectLayer(cfg['image_size'], cfg['heatmap_size'], 'mean')
         ref, _ = layer(fms, cfg['space_size'], [cfg['space_center']], cfg['cube_size'], *one)
-        got = wl.out[0:1].cpu()
-        what = 'frame 0 of the timed output vs oracle ProjectLayer on the same inputs'
+        if wl.out is None:  # --zmax only: the z-max planes and the K z-columns of frame 0
+            C, Z = ref.shape[1], ref.shape[4]
+            idx = wl.col_index[0:1].cpu()
+            ref_cols = torch.gather(torch.flatten(ref, 2, 3).permute(0, 2, 1, 3), dim=1,
+                                    index=idx.view(1, -1, 1, 1).repeat(1, 1, C, Z))
+            ref = torch.cat([ref.max(dim=4)[0].flatten(), ref_cols.flatten()])
+            got = torch.cat([wl.zmax[0:1].cpu().flatten(), wl.cols[0:1].cpu().flatten()])
+            what = ('z-max planes and z-columns of frame 0 vs torch.max / the torch.gather of '
+                    'tempo_detector.py:204-206 on the oracle volume')
+        else:
+            got = wl.out[0:1].cpu()
+            what = 'frame 0 of the timed output vs oracle ProjectLayer on the same inputs'
     else:
         if wl.out is None:
             return None
@@ -714,9 +807,13 @@ def main():
             raise SystemExit('bench.py needs a HIP device (tempo_amd has no CPU path)')
         torch.cuda.set_device(local)
         dev = torch.device('cuda', local)
-    if world > 1:
+    # the dense workload's data path has a collective: at one rank it still runs (a one-rank
+    # RCCL group), so that the all-gather and the slab assembly are timed on hardware
+    if world > 1 or (args.workload == 'dense' and not args.dry_run):
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1:
+            os.environ.setdefault('MASTER_PORT', str(free_port()))
         if args.dry_run:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
@@ -748,8 +845,8 @@ def main():
 
     for _ in range(args.warmup):
         wl.step()
-    block_s = []
-    for _ in range(max(1, args.blocks)):
+
+    def timed_block():
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -760,7 +857,19 @@ def main():
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        block_s.append(el)
+        return el
+
+    # Every block is exactly --steps steps between two barrier + synchronize pairs.  One block
+    # of the default workload lasts a few ms, too short for the clocks to settle or for an
+    # outside observer (the driver samples GPU activity) to see the GPU working: the number
+    # of blocks is raised until the timed region lasts --min-seconds (every rank computes the
+    # same count from the max-over-ranks time of the first block).
+    block_s = [timed_block()]
+    blocks = max(1, args.blocks)
+    if not args.dry_run and block_s[0] > 0:
+        blocks = max(blocks, min(5000, int(args.min_seconds / block_s[0]) + 1))
+    for _ in range(blocks - 1):
+        block_s.append(timed_block())
     elapsed = sorted(block_s)[len(block_s) // 2]
 
     if args.dry_run:
@@ -796,16 +905,51 @@ def main():
         k_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
         r_ms = sum(c.elapsed_time(d) for c, d in rp) / len(rp)
         launches = 1
-    comm_ms = None
-    if args.workload == 'dense' and world > 1:  # the all-gather + permute alone
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        barrier()
-        e0.record()
-        for _ in range(args.steps):
-            wl.full = wl.parallel.gather_z_slabs(wl.out)
-        e1.record()
+    comm_ms = comm = None
+    if args.workload == 'dense':  # the all-gather and the slab assembly alone, separately
+        def ev_ms(fn, n=max(10, args.steps)):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+
+        slabs = wl.parallel.allgather_slabs(wl.out)
+        full = torch.empty(wl.out.shape[:4] + (wl.out.shape[4] * world,), device=dev)
+        ag_ms = ev_ms(lambda: wl.parallel.allgather_slabs(wl.out, out=slabs))
+        as_ms = ev_ms(lambda: wl.parallel.assemble_z_slabs(slabs, out=full))
+        comm_ms = ev_ms(lambda: wl.parallel.gather_z_slabs(wl.out))
+        comm = {'allgather_ms': round(ag_ms, 4), 'assemble_ms': round(as_ms, 4),
+                'allgather_plus_assemble_ms': round(comm_ms, 4), 'ranks': world,
+                'bytes_per_rank': wl.out.numel() * 4}
+        if world == 1:
+            # the 8-rank assembly's traffic on this GPU: the same bytes seen as 8 slabs of
+            # Z/8 planes (values meaningless, the copy pattern is the 8-GPU run's), beside
+            # the torch permute + reshape it replaces
+            B_, C_, X_, Y_, Z_ = wl.out.shape
+            fake = wl.out.view(8, B_, C_, X_, Y_, Z_ // 8)
+            comm['assemble_8_slabs_ms'] = round(ev_ms(
+                lambda: wl.parallel.assemble_z_slabs(fake, out=full)), 4)
+            comm['torch_permute_8_slabs_ms'] = round(ev_ms(
+                lambda: fake.permute(1, 2, 3, 4, 0, 5).reshape(B_, C_, X_, Y_, Z_)), 4)
+        del slabs, full
+
+    cols_ms = None
+    if getattr(wl, 'K', 0):  # --zmax only: the z-column launch alone
+        for _ in range(3):
+            wl.columns()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(20):
+            wl.columns()
+        c1.record()
         torch.cuda.synchronize()
-        comm_ms = e0.elapsed_time(e1) / args.steps
+        cols_ms = c0.elapsed_time(c1) / 20
 
     # parity of what was just timed, and the module-level cost of the same call
     check = module = None
@@ -814,7 +958,7 @@ def main():
         torch.cuda.synchronize()
         check = oracle_check(args, wl, dev)
         if args.workload == 'root' and not args.no_module and wl.groups is None \
-                and not args.channels and not wl.nhwc:
+                and not args.channels and not wl.nhwc and wl.zmax_mode == 'off':
             module = module_timing(args, wl, dev)
 
     # fused epilogue: what the reference's caller does instead (tempo_pose.py:172-176) --
@@ -930,7 +1074,11 @@ def main():
                                      if args.workload == 'dense' else
                                      f'frames x proposals over {world} rank(s), no collective')},
             'timing': {'blocks': len(block_s), 'steps_per_block': args.steps,
-                       'block_ms_per_step': [round(b / args.steps * 1e3, 4) for b in block_s],
+                       'timed_region_s': round(sum(block_s), 3),
+                       'block_ms_per_step': (lambda v: {
+                           'first': v[0], 'min': min(v), 'median': sorted(v)[len(v) // 2],
+                           'max': max(v), 'last': v[-1]})(
+                               [round(b / args.steps * 1e3, 4) for b in block_s]),
                        'reported': 'median block, max over ranks within a block'},
             'roofline': {
                 # `bound` names the yardstick (SURVEY 8d prices the path by HBM bytes);
@@ -938,6 +1086,11 @@ def main():
                 'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 'traffic_source': traffic_src,
+                # the same yardstick on the whole step (every launch of it: repack, gather,
+                # the z-columns), which is what `value` measures
+                'step': {'achieved': round(step_achieved, 1),
+                         'frac': round(step_achieved / HBM_PEAK_GBS, 4),
+                         'ms': round(ms_step, 4)},
                 'step_frac': round(step_achieved / HBM_PEAK_GBS, 4),
                 'limiter': getattr(wl, 'limiter', None),
                 'l2_hit_rate': getattr(measured_traffic, 'l2_hit', None),
@@ -955,6 +1108,9 @@ def main():
         }
         if comm_ms is not None:
             line['allgather_ms'] = round(comm_ms, 4)
+            line['collective'] = comm
+        if cols_ms is not None:
+            line['zcolumns_ms'] = round(cols_ms, 4)
         if check is not None:
             line['oracle_check'] = check
         if module is not None:
@@ -964,7 +1120,10 @@ def main():
         if train is not None:
             line['training_step'] = train
         if world == 1 and not args.no_cpu_baseline:
+            # (last: every GPU phase above is over before the host cores are timed)
             line['cpu_baseline'] = cpu_baseline(args)
+            if getattr(cpu_baseline, 'on_gpu_check', None) is not None:
+                line['oracle_on_gpu_check'] = cpu_baseline.on_gpu_check
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

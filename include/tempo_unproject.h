@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define TEMPO_ABI_VERSION 11
+#define TEMPO_ABI_VERSION 12
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
@@ -111,10 +111,13 @@ int tempo_unproject_root(const float* hm, const float* cam, const float* ax_x,
 
 /* tempo_unproject_root that also emits the volume's maximum over z, the first
  * thing the root detector computes from it (center_net.py:230, torch.max(x,
- * dim=4)); the volume is still written (its z-columns are gathered later,
- * tempo_detector.py:204-206).
- *   zmax : out fp32 [B, C, X, Y], bit-identical to torch.max over the volume
- *          (NaN propagates); cleared on `stream` before the launch. */
+ * dim=4)).
+ *   zmax  : out fp32 [B, C, X, Y], bit-identical to torch.max over the volume
+ *           (NaN propagates); cleared on `stream` before the launch where needed.
+ *   cubes : out fp32 [B, C, X, Y, Z], or NULL: the volume is then never written.
+ *           Its only other consumer in the reference, the K z-columns gathered at
+ *           tempo_detector.py:204-206, can be computed without it
+ *           (tempo_unproject_root_columns). */
 int tempo_unproject_root_zmax(const float* hm, const float* cam, const float* ax_x,
                               const float* ax_y, const float* ax_z, int ax_batched,
                               const uint8_t* live, float* cubes, float* grids,
@@ -143,7 +146,8 @@ int tempo_root_step(const void* const* views, int C_total, int c_begin,
 
 /* tempo_root_step that also returns the volume's maximum over z (what CenterNet
  * computes first, center_net.py:230), as tempo_unproject_root_zmax does per chunk.
- *   zmax : out fp32 [B, C, X, Y], bit-identical to torch.max(cubes, dim=4) */
+ *   zmax  : out fp32 [B, C, X, Y], bit-identical to torch.max(cubes, dim=4)
+ *   cubes : may be NULL (z-max alone, the volume is never written) */
 int tempo_root_step_zmax(const void* const* views, int C_total, int c_begin,
                          const float* cam, const float* ax_x, const float* ax_y,
                          const float* ax_z, int ax_batched, const uint8_t* live,
@@ -188,6 +192,10 @@ int tempo_root_step_static(const void* const* views, int C_total, int c_begin,
  *                 to take a channel slice); rows are W * texel_bytes apart
  *   CP          : tempo_padded_channels(C); the fetch lanes cover CP channels per texel,
  *                 channels C..CP-1 are discarded, so texel_bytes may be as small as 4 * C
+ * The caller vouches for the C channels of every texel and nothing else: a map's buffer
+ * range ends with channel C - 1 of its last texel, so a channel slice at the end of a
+ * tensor is never read past (what the fetch lanes cover beyond it reads as 0 without a
+ * memory access).
  * Pointers 4-byte aligned (16 for full fetch speed).  The repacked buffer is the special
  * case views[v] = hm + v*H*W*CP, frame_bytes = V*H*W*CP*4, texel_bytes = CP*4.
  * Everything else as tempo_unproject_root / tempo_unproject_window. */
@@ -201,7 +209,8 @@ int tempo_unproject_root_views(const void* const* views, long long frame_bytes,
                                void* stream);
 /* tempo_unproject_root_views that also returns the volume's maximum over z, as
  * tempo_unproject_root_zmax does (center_net.py:230):
- *   zmax : out fp32 [B, C, X, Y], bit-identical to torch.max(cubes, dim=4) */
+ *   zmax  : out fp32 [B, C, X, Y], bit-identical to torch.max(cubes, dim=4)
+ *   cubes : may be NULL (z-max alone) */
 int tempo_unproject_root_views_zmax(const void* const* views, long long frame_bytes,
                                     int texel_bytes, const float* cam, const float* ax_x,
                                     const float* ax_y, const float* ax_z, int ax_batched,
@@ -430,6 +439,46 @@ int tempo_window_geometry(const float* grid_center, int B, int cols, const float
  *   out   : fp32 [B, K, C, Z];  a cell outside [0, X*Y) gives zeros (torch raises) */
 int tempo_gather_zcolumns(const float* cubes, const int64_t* index, float* out, int B,
                           int K, int C, int X, int Y, int Z, void* stream);
+
+/* The same z-columns computed directly from the heatmaps: only the K * Z voxels of the K
+ * cells are unprojected (per-voxel arithmetic of tempo_unproject_root, hence bit-identical
+ * to tempo_gather_zcolumns on the volume that call writes), so the root detector
+ * (tempo_detector.py:187-206: volume -> z-max -> 2-D net -> top-K cells -> z-columns -> 1-D
+ * net) never needs the [B, C, X, Y, Z] volume in memory: tempo_*_zmax with cubes = NULL
+ * first, this call once the cells are known.
+ *   index : int64 [B, K], cell = x * Y + y; a cell outside [0, X*Y) gives zeros
+ *   out   : fp32 [B, K, C, Z];  live : [B] bytes or NULL (a skipped item's columns are 0)
+ * Three forms by where the maps are: the repacked buffer hm [B, V, H, W, CP]; channel-last
+ * tensors in place (arguments as tempo_unproject_root_views); the reference's own V NCHW
+ * tensors [B, C_total, H, W] (arguments as tempo_root_step, no workspace: the few texels
+ * needed are read plane by plane). */
+int tempo_unproject_root_columns(const float* hm, const float* cam, const float* ax_x,
+                                 const float* ax_y, const float* ax_z, int ax_batched,
+                                 const uint8_t* live, const int64_t* index, float* out, int B,
+                                 int K, int V, int C, int CP, int H, int W, int X, int Y, int Z,
+                                 float hm_w, float hm_h, float img_w, float img_h,
+                                 int mm_unfused, void* stream);
+int tempo_unproject_root_columns_views(const void* const* views, long long frame_bytes,
+                                       int texel_bytes, const float* cam, const float* ax_x,
+                                       const float* ax_y, const float* ax_z, int ax_batched,
+                                       const uint8_t* live, const int64_t* index, float* out,
+                                       int B, int K, int V, int C, int CP, int H, int W, int X,
+                                       int Y, int Z, float hm_w, float hm_h, float img_w,
+                                       float img_h, int mm_unfused, void* stream);
+int tempo_root_step_columns(const void* const* views, int C_total, int c_begin,
+                            const float* cam, const float* ax_x, const float* ax_y,
+                            const float* ax_z, int ax_batched, const uint8_t* live,
+                            const int64_t* index, float* out, int B, int K, int V, int C,
+                            int CP, int H, int W, int X, int Y, int Z, float hm_w, float hm_h,
+                            float img_w, float img_h, int mm_unfused, void* stream);
+
+/* Multi-GPU dense grids (BASELINE config 5; no counterpart in the reference, whose only
+ * parallelism is DDP, tools/dist_train.sh:12-20): rank r unprojects planes [r*Zr, (r+1)*Zr)
+ * of the grid (tempo_unproject_root with a shorter z axis), ONE all-gather over RCCL leaves
+ * slabs [R][rows][Zr] on every rank (rows = B*C*X*Y), and this call moves the rank index
+ * inside the row:  out [rows][R*Zr] = the volume [B, C, X, Y, Z].  slabs != out. */
+int tempo_assemble_zslabs(const float* slabs, float* out, int R, long long rows, int Zr,
+                          void* stream);
 
 /* Projection only, for parity checks of the coordinate chain
  * (SimpleCameraTorch.world_to_pixel + project_layer.py:113-126):

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TEMPO_LIB') or os.path.join(_HERE, 'lib', 'libtempo_unproject.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _c_void_p, _c_int, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
@@ -72,6 +72,17 @@ SIGNATURES = {
                                   [_c_int, _c_void_p, _c_void_p]),
     'tempo_conv1x1_nhwc': (_c_int, [_c_void_p] * 4 + [_c_int] * 8 + [_c_void_p]),
     'tempo_gather_zcolumns': (_c_int, [_c_void_p] * 3 + [_c_int] * 6 + [_c_void_p]),
+    'tempo_unproject_root_columns': (_c_int, [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 3 +
+                                     [_c_int] * 10 + [_c_float] * 4 + [_c_int, _c_void_p]),
+    'tempo_unproject_root_columns_views': (_c_int, [ctypes.POINTER(_c_void_p), ctypes.c_longlong,
+                                                    _c_int] + [_c_void_p] * 4 + [_c_int] +
+                                           [_c_void_p] * 3 + [_c_int] * 10 + [_c_float] * 4 +
+                                           [_c_int, _c_void_p]),
+    'tempo_root_step_columns': (_c_int, [ctypes.POINTER(_c_void_p), _c_int, _c_int] +
+                                [_c_void_p] * 4 + [_c_int] + [_c_void_p] * 3 + [_c_int] * 10 +
+                                [_c_float] * 4 + [_c_int, _c_void_p]),
+    'tempo_assemble_zslabs': (_c_int, [_c_void_p, _c_void_p, _c_int, ctypes.c_longlong, _c_int,
+                                       _c_void_p]),
     'tempo_window_geometry': (_c_int, [_c_void_p, _c_int, _c_int] + [_c_void_p] * 4 +
                               [_c_int] * 6 + [_c_void_p] * 6),
     'tempo_project_points': (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int] +

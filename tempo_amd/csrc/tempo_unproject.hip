@@ -78,6 +78,9 @@ constexpr unsigned kInvalid = 0x80000000u;  // >= any view's byte size (host-che
 constexpr int kBrickEdge = 4;  // voxels per edge of a brick (window brick kernels)
 constexpr int MODE_ROOT = 0;
 constexpr int MODE_WINDOW = 1;
+// the root grid's arithmetic on K z-columns per item picked by a cell index (the detector's
+// second stage, tempo_detector.py:204-206): voxel n = k * Z + z of the virtual [1, K, Z] grid
+constexpr int MODE_COLUMNS = 2;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef tempo_f2 f32x2;
@@ -133,8 +136,15 @@ struct UnprojArgs {
   // (torch.channels_last) are both of this form.
   const char* vbase[TEMPO_MAX_VIEWS];
   long long frame_bytes;
-  unsigned map_bytes;  // H * row_bytes: the buffer range of one map
+  unsigned map_bytes;  // the buffer range of one map (bytes the fetches may touch)
   int texel_bytes, row_bytes;
+  // MODE_COLUMNS: cell index [NB][K] (cell = x * Y + y of the fdim[0] x fdim[1] root grid),
+  // output [NB][K][C][dim[2]]; plane_bytes != 0: the maps are NCHW (channel c of a texel lies
+  // c * plane_bytes further on), read with one 4-byte load per channel
+  const long long* col_index;
+  float* col_out;
+  int K;
+  unsigned plane_bytes;
 };
 
 __device__ __forceinline__ int slot_view(const UnprojArgs& a, int slot) {
@@ -420,6 +430,17 @@ __device__ __forceinline__ bool voxel_world(const UnprojArgs& a, int b, int n,
     *y = a.ax[1][b * a.ax_stride[1] + i1];
     *z = a.ax[2][b * a.ax_stride[2] + i2];
     return true;
+  } else if (MODE == MODE_COLUMNS) {
+    // column i1 of item b stands at the grid cell its index names; a cell outside the grid
+    // gives a column of zeros (as tempo_gather_zcolumns does)
+    const long long cell = a.col_index[(long long)b * a.K + i1];
+    if (cell < 0 || cell >= (long long)a.fdim[0] * a.fdim[1]) return false;
+    const int cx = (int)(cell / a.fdim[1]);
+    const int cy = (int)(cell - (long long)cx * a.fdim[1]);
+    *x = a.ax[0][b * a.ax_stride[0] + cx];
+    *y = a.ax[1][b * a.ax_stride[1] + cy];
+    *z = a.ax[2][b * a.ax_stride[2] + i2];
+    return true;
   } else {
     const int f0 = uniform_load(a.tl, 3 * b + 0) + i0;
     const int f1 = uniform_load(a.tl, 3 * b + 1) + i1;
@@ -504,7 +525,7 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
       // root: a view that fails the bounds test is multiplied by 0 in the
       // reference, so its texels are never fetched -- unless a coordinate is
       // NaN: then the reference's 0 * NaN poisons the voxel and so must we
-      need = MODE != MODE_ROOT || p.inside || p.px != p.px || p.py != p.py;
+      need = MODE == MODE_WINDOW || p.inside || p.px != p.px || p.py != p.py;
     }
     cnt += p.inside;
     mbits |= (unsigned)p.inside << view;
@@ -517,17 +538,24 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
       // past 2^31) or >= view_bytes, and the buffer load returns 0 for it
       // a lane that does not need the view fetches nothing either; its weights
       // are finite, so its (all-zero) texels mix to 0
-      const bool x0ok = need && (unsigned)t.x0 < (unsigned)a.W;
-      const bool x1ok = need && (unsigned)(t.x0 + 1) < (unsigned)a.W;
+      bool x0ok = need && (unsigned)t.x0 < (unsigned)a.W;
+      bool x1ok = need && (unsigned)(t.x0 + 1) < (unsigned)a.W;
+      // (columns on planar maps: a row outside the map would land in a neighbouring
+      // channel's plane instead of outside the buffer, so the rows are tested as well)
+      bool r0ok = true, r1ok = true;
+      if (MODE == MODE_COLUMNS) {
+        r0ok = (unsigned)t.y0 < (unsigned)a.H;
+        r1ok = (unsigned)(t.y0 + 1) < (unsigned)a.H;
+      }
       // 24-bit multiply-adds (full rate; y0, x0, the row pitch and the texel pitch are
       // far below 2^23: host-checked)
       const unsigned base = (unsigned)texel_offset(t.y0, t.x0, a.row_bytes, a.texel_bytes);
       const unsigned row = (unsigned)a.row_bytes, tb = (unsigned)a.texel_bytes;
       u32x4 off;
-      off.x = x0ok ? base : kInvalid;
-      off.y = x1ok ? base + tb : kInvalid;
-      off.z = x0ok ? base + row : kInvalid;
-      off.w = x1ok ? base + row + tb : kInvalid;
+      off.x = x0ok && r0ok ? base : kInvalid;
+      off.y = x1ok && r0ok ? base + tb : kInvalid;
+      off.z = x0ok && r1ok ? base + row : kInvalid;
+      off.w = x1ok && r1ok ? base + row + tb : kInvalid;
       const float4 wt = make_float4(t.nw, t.ne, t.sw, t.se);
 #if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 1  // no gather traffic
       off.x = off.y = off.z = off.w = kInvalid;
@@ -565,14 +593,27 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
 #pragma unroll
       for (int g = 0; g < G; g++) {
         const int s = s0 + g;
-        if (s < NSUB) {
+        // (columns: short waves, sub-steps past the wave's voxels are skipped -- wave-uniform)
+        if (s < NSUB && (MODE != MODE_COLUMNS || s * VPS < a.wave_vox)) {
           const int vsl = s * VPS + vq;
           const int rd = (lane_on && vsl < kWaveVox) ? vsl : 0;
           const u32x4 o = s_off[buf * kWaveVox + rd];
-          tex[g][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.x + lo, 0, 0);
-          tex[g][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.y + lo, 0, 0);
-          tex[g][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.z + lo, 0, 0);
-          tex[g][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.w + lo, 0, 0);
+          if (MODE == MODE_COLUMNS && a.plane_bytes != 0) {
+            // NCHW maps: channel 4 cq + j of a texel lies (4 cq + j) planes further on; a
+            // channel past the slice is past the buffer's range and reads as 0
+            const unsigned ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+              for (int j = 0; j < 4; j++)
+                tex[g][t][j] = __builtin_amdgcn_raw_buffer_load_b32(
+                    rs, ov[t] + (unsigned)(4 * cq + j) * a.plane_bytes, 0, 0);
+          } else {
+            tex[g][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.x + lo, 0, 0);
+            tex[g][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.y + lo, 0, 0);
+            tex[g][2] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.z + lo, 0, 0);
+            tex[g][3] = __builtin_amdgcn_raw_buffer_load_b128(rs, o.w + lo, 0, 0);
+          }
         }
       }
     };
@@ -580,7 +621,7 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
 #pragma unroll
       for (int g = 0; g < G; g++) {
         const int s = s0 + g;
-        if (s < NSUB) {
+        if (s < NSUB && (MODE != MODE_COLUMNS || s * VPS < a.wave_vox)) {
           const int vsl = s * VPS + vq;
           const int rd = (lane_on && vsl < kWaveVox) ? vsl : 0;
           const float4 w = s_wt[buf * kWaveVox + rd];
@@ -646,7 +687,7 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
   // phase A layout, handed to the voxel's L channel lanes through LDS
   {
     reinterpret_cast<DenRec*>(wbase)[lane] =
-        make_den((MODE == MODE_ROOT ? (float)cnt : (float)a.V) + 1e-6f);
+        make_den((MODE != MODE_WINDOW ? (float)cnt : (float)a.V) + 1e-6f);
     if (MODE == MODE_ROOT && a.mask != nullptr && lane < a.wave_vox && n < a.N) {
       char* m = (char*)a.mask + ((long long)b * a.N + n) * a.mask_bytes;
       if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mbits;
@@ -811,6 +852,45 @@ template <int MODE, int L, int SB, int UNF>
 __global__ __launch_bounds__(kTileWaves * 64) void unproject_kernel(const UnprojArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   unproject_block<MODE, L, SB, UNF>(a, blockIdx.x, smem);
+}
+
+// ------------------------------------------------- root grid, K z-columns per item
+// The root detector's second stage reads the z-columns of its K best (x, y) cells
+// (tempo_detector.py:204-206).  Instead of gathering them out of a written volume this kernel
+// computes exactly those K * Z voxels: the same per-voxel arithmetic (unproject_wave), so the
+// values are bit-identical to the volume's, and the volume itself need never exist.  One wave
+// = 64 consecutive (column, z) pairs of one item; output [NB][K][C][Z].
+template <int L, int UNF>
+__global__ __launch_bounds__(kTileWaves * 64) void unproject_columns_kernel(const UnprojArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int item = blockIdx.x;
+  if (item >= a.total) return;
+  const int b = __builtin_amdgcn_readfirstlane(item / a.tiles);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // short waves (a.wave_vox = 16 voxels): the launch is a few thousand voxels, bound by the
+  // latency of its dependent fetches, so it wants many waves rather than full ones
+  const int n0 = (item - b * a.tiles) * a.tile_vox + wave * a.wave_vox;
+  if (n0 >= a.N) return;
+  unsigned char* wbase = smem + (size_t)wave * wave_lds_bytes(L);
+  const int n = n0 + lane;
+  const bool mine = lane < a.wave_vox && n < a.N;
+  int k = 0, i2 = 0, unused = 0;
+  if (mine) voxel_index(a, n, &unused, &k, &i2);
+  const int Z = a.dim[2];
+  float* dst = a.col_out + (((long long)b * a.K + k) * a.C) * Z + i2;  // + ch * Z
+  const bool dead = (a.live != nullptr && uniform_load_u8(a.live, b) == 0);
+  if (dead) {
+    if (mine)
+      for (int ch = 0; ch < a.C; ch++) dst[ch * Z] = 0.0f;
+    return;
+  }
+  unproject_wave<MODE_COLUMNS, L, 4, UNF>(a, b, b, n0, lane, wbase);
+  constexpr int TSTR = kWaveVox + 1;
+  const float* s_out = reinterpret_cast<const float*>(wbase);
+  if (mine)
+    for (int ch = 0; ch < a.C; ch++) dst[ch * Z] = s_out[ch * TSTR + lane];
 }
 
 // --------------------------------------------- window + axis-max planes, fused
@@ -1964,6 +2044,35 @@ __global__ __launch_bounds__(kThreads) void zcolumns_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------ z-slab assembly
+// Multi-GPU dense grids: rank r computes planes [r * Zr, (r + 1) * Zr) of every (b, c, x, y)
+// column, one all-gather leaves [R][rows][Zr] on every rank (rows = B * C * X * Y), and the
+// volume [rows][R * Zr] is that with the rank index moved inside the row.  One thread per
+// output quad (or float when Zr is not a multiple of 4); the gathered buffer is read once
+// (streaming loads), the writes are contiguous.
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void assemble_zslabs_kernel(const float* __restrict__ in,
+                                                                   float* __restrict__ out,
+                                                                   int R, long long rows,
+                                                                   int Zr) {
+  const int per_row = R * Zr / VEC;  // output elements (of VEC floats) per row
+  const long long total = rows * per_row;
+  for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total;
+       i += (long long)gridDim.x * kThreads) {
+    const long long row = i / per_row;
+    const int q = (int)(i - row * per_row) * VEC;
+    const int r = q / Zr, zr = q - r * Zr;
+    const float* src = in + ((long long)r * rows + row) * Zr + zr;
+    if (VEC == 4) {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src));
+      *reinterpret_cast<f4*>(out + i * 4) = v;
+    } else {
+      out[i] = __builtin_nontemporal_load(src);
+    }
+  }
+}
+
 // ---------------------------------------------------------- window geometry
 // project_layer.py:299-324 for all windows of a call in one launch (the reference spends
 // about fifteen tiny tensor ops on it, per candidate and timestep).  One thread per window;
@@ -2208,6 +2317,36 @@ int launch_mode(const UnprojArgs& a, int mm_unfused, hipStream_t stream) {
   return TEMPO_E_ARG;
 }
 
+template <int L, int UNF>
+int launch_columns_one(const UnprojArgs& a, hipStream_t stream) {
+  UnprojArgs k = a;
+  fill_order_magic(k.order, k.magic, a.V, a.dim);
+  k.wave_vox = 16;
+  k.tile_vox = kTileWaves * k.wave_vox;
+  k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
+  const long long total = (long long)a.NB * k.tiles;
+  if (total > 0x7fffffffLL) return TEMPO_E_DIM;
+  k.total = (int)total;
+  hipLaunchKernelGGL((unproject_columns_kernel<L, UNF>), dim3((unsigned)k.total),
+                     dim3(kTileWaves * 64), (size_t)kTileWaves * wave_lds_bytes(L), stream, k);
+  return (int)hipGetLastError();
+}
+
+int launch_columns(const UnprojArgs& a, int mm_unfused, hipStream_t stream) {
+#define TEMPO_COL_CASE(LL)                                                       \
+  case LL:                                                                       \
+    return mm_unfused ? launch_columns_one<LL, 1>(a, stream) : launch_columns_one<LL, 0>(a, stream);
+  switch (a.CP / 4) {
+    TEMPO_COL_CASE(4)
+    TEMPO_COL_CASE(5)
+    TEMPO_COL_CASE(6)
+    TEMPO_COL_CASE(7)
+    TEMPO_COL_CASE(8)
+    default: return TEMPO_E_PAD;
+  }
+#undef TEMPO_COL_CASE
+}
+
 // 16-byte alignment of a device pointer the kernels access with 128-bit loads / stores
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -2233,6 +2372,10 @@ struct Layout {
   const void* const* views = nullptr;
   long long frame_bytes = 0;
   int texel_bytes = 0;
+  // planar: `views` are V NCHW tensors [F][C_total][H][W], channels [c_begin, c_begin + C)
+  // (the columns kernel only)
+  bool planar = false;
+  int C_total = 0, c_begin = 0;
 };
 
 // fills the forward kernels' layout fields of `a` (a.V, a.H, a.W, a.CP set); TEMPO_OK or an
@@ -2247,6 +2390,23 @@ int apply_layout(UnprojArgs& a, const Layout& lay) {
     a.frame_bytes = (long long)a.V * a.H * a.row_bytes;
     for (int v = 0; v < a.V; v++)
       a.vbase[v] = reinterpret_cast<const char*>(lay.hm) + (long long)v * a.H * a.row_bytes;
+  } else if (lay.planar) {
+    if (lay.views == nullptr) return TEMPO_E_NULL;
+    if (lay.c_begin < 0 || lay.c_begin + a.C > lay.C_total) return TEMPO_E_DIM;
+    const long long plane = (long long)a.H * a.W * 4;
+    if (plane * a.C >= 0x80000000LL) return TEMPO_E_SIZE;
+    a.texel_bytes = 4;
+    a.row_bytes = a.W * 4;
+    a.plane_bytes = (unsigned)plane;
+    a.frame_bytes = plane * lay.C_total;
+    for (int v = 0; v < a.V; v++) {
+      if (lay.views[v] == nullptr) return TEMPO_E_NULL;
+      if (reinterpret_cast<uintptr_t>(lay.views[v]) % 4 != 0) return TEMPO_E_ARG;
+      a.vbase[v] = static_cast<const char*>(lay.views[v]) + plane * lay.c_begin;
+    }
+    if (a.row_bytes >= (1 << 23) || a.H >= (1 << 23)) return TEMPO_E_SIZE;
+    a.map_bytes = (unsigned)(plane * a.C);  // the slice's C planes, nothing beyond
+    return TEMPO_OK;
   } else {
     if (lay.views == nullptr) return TEMPO_E_NULL;
     // texels may be narrower than the CP channels a fetch covers (the tail of the last
@@ -2266,7 +2426,13 @@ int apply_layout(UnprojArgs& a, const Layout& lay) {
   if ((long long)a.H * a.row_bytes >= 0x80000000LL || a.row_bytes >= (1 << 23) ||
       a.H >= (1 << 23))
     return TEMPO_E_SIZE;
-  a.map_bytes = (unsigned)((long long)a.H * a.row_bytes);
+  // The buffer range of one map ends with the C-th channel of its last texel: the caller
+  // vouches for the C channels of every texel and for nothing behind them (a channel slice
+  // of a wider tensor is handed over as a shifted pointer, so H * row_bytes from there
+  // would reach past the tensor's end).  The fetch lanes cover CP channels; 16-byte buffer
+  // loads are range-checked dword by dword, so what lies past the range reads as 0 and
+  // causes no memory access (tools/range_check.hip).
+  a.map_bytes = (unsigned)((long long)a.H * a.row_bytes - a.texel_bytes + 4ll * a.C);
   return TEMPO_OK;
 }
 
@@ -2529,7 +2695,12 @@ int root_impl(const Layout& lay, const float* cam, const float* ax_x, const floa
               int W, int X, int Y, int Z, float hm_w, float hm_h, float img_w, float img_h,
               int mm_unfused, const int32_t* groups, int num_groups, const Extra& ex,
               void* stream) {
-  if (!cam || !ax_x || !ax_y || !ax_z || !cubes) return TEMPO_E_NULL;
+  if (!cam || !ax_x || !ax_y || !ax_z) return TEMPO_E_NULL;
+  // the volume may be left out only where another output is asked for: the z-max planes
+  // (plain forward launch: not grouped, not training, not backward)
+  if (!cubes && (ex.zmax == nullptr || groups != nullptr || ex.cmask != nullptr ||
+                 ex.ghm != nullptr))
+    return TEMPO_E_NULL;
   if ((groups == nullptr) != (num_groups == 0) || num_groups < 0 || num_groups > B)
     return TEMPO_E_ARG;
   const int rc = check_common(V, C, CP, H, W);
@@ -2600,7 +2771,8 @@ int root_step_impl(const void* const* views, int C_total, int c_begin, const flo
                    int mask_bytes, int B, int V, int C, int CP, int H, int W, int X, int Y,
                    int Z, float hm_w, float hm_h, float img_w, float img_h, int mm_unfused,
                    float* zmax, float* workspace, int chunk, void* stream) {
-  if (views == nullptr || workspace == nullptr || cam == nullptr || cubes == nullptr)
+  if (views == nullptr || workspace == nullptr || cam == nullptr ||
+      (cubes == nullptr && zmax == nullptr))
     return TEMPO_E_NULL;
   const int rc = check_common(V, C, CP, H, W);
   if (rc != TEMPO_OK) return rc;
@@ -2627,7 +2799,8 @@ int root_step_impl(const void* const* views, int C_total, int c_begin, const flo
                     ax_x + (ax_batched ? (long long)b0 * X : 0),
                     ax_y + (ax_batched ? (long long)b0 * Y : 0),
                     ax_z + (ax_batched ? (long long)b0 * Z : 0), ax_batched,
-                    live ? live + b0 : nullptr, cubes + (long long)b0 * C * N,
+                    live ? live + b0 : nullptr,
+                    cubes ? cubes + (long long)b0 * C * N : nullptr,
                     grids ? grids + (long long)b0 * N * 3 : nullptr,
                     mask ? static_cast<char*>(mask) + (long long)b0 * N * mask_bytes : nullptr,
                     mask_bytes, n, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w, img_h,
@@ -2658,7 +2831,7 @@ int tempo_root_step_zmax(const void* const* views, int C_total, int c_begin, con
                          int X, int Y, int Z, float hm_w, float hm_h, float img_w, float img_h,
                          int mm_unfused, float* zmax, float* workspace, int chunk,
                          void* stream) {
-  if (zmax == nullptr) return TEMPO_E_NULL;
+  if (zmax == nullptr) return TEMPO_E_NULL;  // (cubes may be NULL: z-max alone)
   return root_step_impl(views, C_total, c_begin, cam, ax_x, ax_y, ax_z, ax_batched, live, cubes,
                         grids, mask, mask_bytes, B, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w,
                         img_h, mm_unfused, zmax, workspace, chunk, stream);
@@ -2901,7 +3074,85 @@ int window_impl(const Layout& lay, const float* cam, const int32_t* win_frame, c
 
 }  // namespace
 
+namespace {
+
+int columns_impl(const Layout& lay, const float* cam, const float* ax_x, const float* ax_y,
+                 const float* ax_z, int ax_batched, const uint8_t* live, const int64_t* index,
+                 float* out, int B, int K, int V, int C, int CP, int H, int W, int X, int Y,
+                 int Z, float hm_w, float hm_h, float img_w, float img_h, int mm_unfused,
+                 void* stream) {
+  if (!cam || !ax_x || !ax_y || !ax_z || !index || !out) return TEMPO_E_NULL;
+  const int rc = check_common(V, C, CP, H, W);
+  if (rc != TEMPO_OK) return rc;
+  if (B <= 0 || K <= 0 || X <= 0 || Y <= 0 || Z <= 0) return TEMPO_E_DIM;
+  if ((long long)X * Y >= 0x7fffffffLL || (long long)K * Z >= 0x7fffffffLL / 4 ||
+      (long long)K * Z * C * 4 >= 0x80000000LL)
+    return TEMPO_E_SIZE;
+  if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
+  UnprojArgs a = {};
+  a.cam = cam;
+  a.ax[0] = ax_x; a.ax[1] = ax_y; a.ax[2] = ax_z;
+  a.ax_stride[0] = ax_batched ? X : 0;
+  a.ax_stride[1] = ax_batched ? Y : 0;
+  a.ax_stride[2] = ax_batched ? Z : 0;
+  a.live = live;
+  a.frame_stride = (long long)V * H * W * CP;
+  a.view_bytes = (unsigned)((long long)H * W * CP * 4);
+  a.NB = B; a.F = B; a.V = V; a.C = C; a.CP = CP; a.H = H; a.W = W;
+  a.dim[0] = 1; a.dim[1] = K; a.dim[2] = Z; a.N = K * Z;  // the virtual grid of the columns
+  a.fdim[0] = X; a.fdim[1] = Y; a.fdim[2] = Z;            // the root grid the cells index
+  a.geom = tempo_make_geom(hm_w, hm_h, img_w, img_h);
+  a.col_index = reinterpret_cast<const long long*>(index);
+  a.col_out = out;
+  a.K = K;
+  const int lrc = apply_layout(a, lay);
+  if (lrc != TEMPO_OK) return lrc;
+  return launch_columns(a, mm_unfused, (hipStream_t)stream);
+}
+
+}  // namespace
+
 extern "C" {
+
+int tempo_unproject_root_columns(const float* hm, const float* cam, const float* ax_x,
+                                 const float* ax_y, const float* ax_z, int ax_batched,
+                                 const uint8_t* live, const int64_t* index, float* out, int B,
+                                 int K, int V, int C, int CP, int H, int W, int X, int Y, int Z,
+                                 float hm_w, float hm_h, float img_w, float img_h,
+                                 int mm_unfused, void* stream) {
+  if (!hm) return TEMPO_E_NULL;
+  Layout lay;
+  lay.hm = hm;
+  return columns_impl(lay, cam, ax_x, ax_y, ax_z, ax_batched, live, index, out, B, K, V, C, CP,
+                      H, W, X, Y, Z, hm_w, hm_h, img_w, img_h, mm_unfused, stream);
+}
+
+int tempo_unproject_root_columns_views(const void* const* views, long long frame_bytes,
+                                       int texel_bytes, const float* cam, const float* ax_x,
+                                       const float* ax_y, const float* ax_z, int ax_batched,
+                                       const uint8_t* live, const int64_t* index, float* out,
+                                       int B, int K, int V, int C, int CP, int H, int W, int X,
+                                       int Y, int Z, float hm_w, float hm_h, float img_w,
+                                       float img_h, int mm_unfused, void* stream) {
+  if (!views) return TEMPO_E_NULL;
+  Layout lay;
+  lay.views = views; lay.frame_bytes = frame_bytes; lay.texel_bytes = texel_bytes;
+  return columns_impl(lay, cam, ax_x, ax_y, ax_z, ax_batched, live, index, out, B, K, V, C, CP,
+                      H, W, X, Y, Z, hm_w, hm_h, img_w, img_h, mm_unfused, stream);
+}
+
+int tempo_root_step_columns(const void* const* views, int C_total, int c_begin,
+                            const float* cam, const float* ax_x, const float* ax_y,
+                            const float* ax_z, int ax_batched, const uint8_t* live,
+                            const int64_t* index, float* out, int B, int K, int V, int C,
+                            int CP, int H, int W, int X, int Y, int Z, float hm_w, float hm_h,
+                            float img_w, float img_h, int mm_unfused, void* stream) {
+  if (!views) return TEMPO_E_NULL;
+  Layout lay;
+  lay.views = views; lay.planar = true; lay.C_total = C_total; lay.c_begin = c_begin;
+  return columns_impl(lay, cam, ax_x, ax_y, ax_z, ax_batched, live, index, out, B, K, V, C, CP,
+                      H, W, X, Y, Z, hm_w, hm_h, img_w, img_h, mm_unfused, stream);
+}
 
 int tempo_conv1x1_nhwc(const float* in, const float* weight, const float* bias, float* out,
                        int T, int V, int B, int K, int C, int CP, int H, int W, void* stream) {
@@ -2953,6 +3204,24 @@ int tempo_window_geometry(const float* grid_center, int B, int cols, const float
   a.tl = tl; a.start = start; a.end = end; a.offset = offset; a.live = live;
   hipLaunchKernelGGL(window_geometry_kernel, dim3((B + kThreads - 1) / kThreads), dim3(kThreads),
                      0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int tempo_assemble_zslabs(const float* slabs, float* out, int R, long long rows, int Zr,
+                          void* stream) {
+  if (!slabs || !out) return TEMPO_E_NULL;
+  if (R <= 0 || rows <= 0 || Zr <= 0 || (long long)R * Zr > 0x7fffffffLL) return TEMPO_E_DIM;
+  if (slabs == out) return TEMPO_E_ARG;
+  const bool vec = Zr % 4 == 0 && aligned16(slabs) && aligned16(out);
+  const long long total = rows * ((long long)R * Zr / (vec ? 4 : 1));
+  long long blocks = (total + kThreads - 1) / kThreads;
+  if (blocks > 256 * 64) blocks = 256 * 64;  // grid-stride beyond 64 workgroups per CU
+  if (vec)
+    hipLaunchKernelGGL((assemble_zslabs_kernel<4>), dim3((unsigned)blocks), dim3(kThreads), 0,
+                       (hipStream_t)stream, slabs, out, R, rows, Zr);
+  else
+    hipLaunchKernelGGL((assemble_zslabs_kernel<1>), dim3((unsigned)blocks), dim3(kThreads), 0,
+                       (hipStream_t)stream, slabs, out, R, rows, Zr);
   return (int)hipGetLastError();
 }
 

@@ -41,6 +41,16 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _no_grad_path(what, *tensors):
+    """Forward-only entry points raise when autograd would expect a gradient through them
+    (the torch expressions they replace carry one); silently cutting the graph would train
+    on wrong gradients."""
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise NotImplementedError(
+            f'{what} is forward-only: call it under torch.no_grad() / on detached tensors, '
+            'or use the torch expression it replaces for a training step')
+
+
 def _need(t, dtype, name, device=None):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise TypeError(f'{name}: expected a tensor on a HIP device (tempo_amd has no CPU path)')
@@ -326,14 +336,15 @@ def mask_dtype(num_views):
 
 def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, channels=None,
               live=None, want_grids=False, want_mask=False, out=None, mm_mode='auto',
-              chunk=None, hm_buf=None, in_library=True, zmax_out=None):
+              chunk=None, hm_buf=None, in_library=True, zmax_out=None, want_cubes=True):
     """Repack + root unprojection of a whole batch, in chunks of ``chunk`` frames
     (default :func:`chunk_frames`: 16 at config 2) that reuse one channel-last buffer: a
     chunk's maps stay in the 256 MB Infinity Cache between the repack that writes them and
     the gather that reads them, instead of making a round trip through HBM (config 2:
     0.39 -> 0.28 ms per 32-frame step).  Arguments as :func:`repack_nhwc` +
     :func:`unproject_root`; ``axes`` and ``live`` may be per batch item.  Returns
-    ``(cubes, grids | None, mask | None)``."""
+    ``(cubes, grids | None, mask | None)``.  ``want_cubes=False`` (with ``zmax_out``): the
+    z-max planes alone, the volume is never written (``cubes`` is None)."""
     fm0 = feature_maps[0]
     dev = fm0.device
     B, C_total, H, W = fm0.shape
@@ -342,7 +353,11 @@ def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, chan
     chunk = chunk_frames(V, H, W, padded_channels(C)) if chunk is None else int(chunk)
     X, Y, Z = (int(a.shape[-1]) for a in axes)
     N = X * Y * Z
-    if out is None:
+    if not want_cubes:
+        if zmax_out is None:
+            raise ValueError('want_cubes=False needs zmax_out (some output must be asked for)')
+        out = None
+    elif out is None:
         out = torch.empty(B, C, X, Y, Z, dtype=torch.float32, device=dev)
     grids = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if want_grids else None
     mask = torch.empty(B, N, dtype=mask_dtype(V)[1], device=dev) if want_mask else None
@@ -357,7 +372,8 @@ def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, chan
         hm = repack_nhwc(feature_maps, c_begin, C, out=None if hm_buf is None else hm_buf[:B])
         unproject_root(hm, cam, axes, C, heatmap_size, image_size, live=live,
                        want_grids=want_grids, want_mask=want_mask, out=out, mm_mode=mm_mode,
-                       grids_out=grids, mask_out=mask, zmax_out=zmax_out)
+                       grids_out=grids, mask_out=mask, zmax_out=zmax_out,
+                       want_cubes=want_cubes)
         return out, grids, mask
     cp = padded_channels(C)
     if hm_buf is None:
@@ -370,10 +386,12 @@ def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, chan
         hm = repack_nhwc([fm[sl] for fm in feature_maps], c_begin, C, out=hm_buf[:n])
         unproject_root(hm, cam[sl], [a[sl] for a in axes] if batched else axes, C,
                        heatmap_size, image_size, live=None if live is None else live[sl],
-                       want_grids=want_grids, want_mask=want_mask, out=out[sl],
+                       want_grids=want_grids, want_mask=want_mask,
+                       out=None if out is None else out[sl],
                        mm_mode=mm_mode, grids_out=None if grids is None else grids[sl],
                        mask_out=None if mask is None else mask[sl],
-                       zmax_out=None if zmax_out is None else zmax_out[sl])
+                       zmax_out=None if zmax_out is None else zmax_out[sl],
+                       want_cubes=want_cubes)
     return out, grids, mask
 
 
@@ -414,9 +432,12 @@ def _root_step_library(feature_maps, cam, axes, heatmap_size, image_size, c_begi
         _need(live, torch.uint8, 'live', dev)
         if live.numel() != B:
             raise ValueError('live must have B entries')
-    _need(out, torch.float32, 'out', dev)
-    if out.numel() != B * C * X * Y * Z:
-        raise ValueError('out has the wrong size')
+    if out is not None:
+        _need(out, torch.float32, 'out', dev)
+        if out.numel() != B * C * X * Y * Z:
+            raise ValueError('out has the wrong size')
+    elif zmax is None:
+        raise ValueError('no output asked for')
     need = int(lib.tempo_root_step_workspace(B, V, H, W, cp, chunk))
     if workspace is None or workspace.numel() < need:
         workspace = _staging(dev, need)
@@ -441,7 +462,8 @@ def _root_step_library(feature_maps, cam, axes, heatmap_size, image_size, c_begi
 
 def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
                    want_grids=False, want_mask=False, out=None, mm_mode='auto',
-                   groups=None, clamp_mask=None, grids_out=None, mask_out=None, zmax_out=None):
+                   groups=None, clamp_mask=None, grids_out=None, mask_out=None, zmax_out=None,
+                   want_cubes=True):
     """Root-grid unprojection on a repacked heatmap tensor.
 
     hm ``[B,V,H,W,CP]``; cam ``[B,V,32]``; axes = (ax_x, ax_y, ax_z), each
@@ -469,7 +491,11 @@ def unproject_root(hm, cam, axes, channels, heatmap_size, image_size, live=None,
         _need(live, torch.uint8, 'live', dev)
         if live.numel() != B:
             raise ValueError('live must have B entries')
-    if out is None:
+    if not want_cubes:  # z-max planes alone: the volume is never written
+        if zmax_out is None:
+            raise ValueError('want_cubes=False needs zmax_out')
+        out = None
+    elif out is None:
         out = torch.empty(B, C, X, Y, Z, dtype=torch.float32, device=dev)
     else:
         _need(out, torch.float32, 'out', dev)
@@ -710,7 +736,7 @@ def channels_last_layout(feature_maps, c_begin=0):
 
 def unproject_root_views(layout, cam, axes, channels, heatmap_size, image_size, live=None,
                          want_grids=False, want_mask=False, out=None, mm_mode='auto',
-                         zmax_out=None):
+                         zmax_out=None, want_cubes=True):
     """:func:`unproject_root` on heatmaps in place (any :class:`MapLayout`); ``zmax_out``
     ``[B,C,X,Y]`` also receives the volume's maximum over z (center_net.py:230)."""
     lib = _lib.load()
@@ -727,7 +753,11 @@ def unproject_root_views(layout, cam, axes, channels, heatmap_size, image_size, 
     CP = padded_channels(C)
     if live is not None:
         _need(live, torch.uint8, 'live', dev)
-    if out is None:
+    if not want_cubes:
+        if zmax_out is None:
+            raise ValueError('want_cubes=False needs zmax_out')
+        out = None
+    elif out is None:
         out = torch.empty(B, C, X, Y, Z, dtype=torch.float32, device=dev)
     else:
         _need(out, torch.float32, 'out', dev)
@@ -864,6 +894,7 @@ def gather_zcolumns(cubes, index, out=None):
     (``tempo_detector.py:204-206``)."""
     lib = _lib.load()
     dev = cubes.device
+    _no_grad_path('gather_zcolumns', cubes)
     _need(cubes, torch.float32, 'cubes')
     _need(index, torch.int64, 'index', dev)
     B, C, X, Y, Z = (int(v) for v in cubes.shape)
@@ -883,6 +914,114 @@ def gather_zcolumns(cubes, index, out=None):
     return out
 
 
+def assemble_zslabs(slabs, out=None):
+    """``slabs [R,B,C,X,Y,Zr]`` (what one all-gather of the ranks' z-slabs leaves) ->
+    the volume ``[B,C,X,Y,R*Zr]`` (``tempo_assemble_zslabs``)."""
+    lib = _lib.load()
+    dev = slabs.device
+    _need(slabs, torch.float32, 'slabs')
+    R, B, C, X, Y, Zr = (int(v) for v in slabs.shape)
+    if out is None:
+        out = torch.empty(B, C, X, Y, R * Zr, dtype=torch.float32, device=dev)
+    else:
+        _need(out, torch.float32, 'out', dev)
+        if out.numel() != slabs.numel():
+            raise ValueError('out has the wrong size')
+    with torch.cuda.device(dev):
+        rc = lib.tempo_assemble_zslabs(_ptr(slabs), _ptr(out), R, B * C * X * Y, Zr,
+                                       _stream_ptr(dev))
+    _lib.check(rc, 'tempo_assemble_zslabs')
+    return out
+
+
+def _columns_common(cam, axes, index, B, V, channels, live, out, dev):
+    _need(cam, torch.float32, 'cam', dev)
+    if tuple(cam.shape) != (B, V, 32):
+        raise ValueError(f'cam must be [{B},{V},32], got {tuple(cam.shape)}')
+    ax = [_need(a, torch.float32, 'axes', dev) for a in axes]
+    batched = ax[0].dim() == 2
+    for a in ax:
+        if (a.dim() == 2) != batched or (batched and a.shape[0] != B):
+            raise ValueError('axes must be all [n] or all [B,n]')
+    X, Y, Z = (int(a.shape[-1]) for a in ax)
+    _need(index, torch.int64, 'index', dev)
+    if index.dim() != 2 or index.shape[0] != B:
+        raise ValueError(f'index must be int64 [{B},K]')
+    K = int(index.shape[1])
+    C = int(channels)
+    if live is not None:
+        _need(live, torch.uint8, 'live', dev)
+        if live.numel() != B:
+            raise ValueError('live must have B entries')
+    if out is None:
+        out = torch.empty(B, K, C, Z, dtype=torch.float32, device=dev)
+    else:
+        _need(out, torch.float32, 'out', dev)
+        if out.numel() != B * K * C * Z:
+            raise ValueError('out has the wrong size')
+    return ax, batched, (X, Y, Z), K, C, out
+
+
+def unproject_root_columns(maps, cam, axes, index, heatmap_size, image_size, channels=None,
+                           c_begin=0, live=None, out=None, mm_mode='auto'):
+    """The z-columns of the root volume at ``index`` int64 ``[B,K]`` (cell = x * Y + y)
+    computed straight from the heatmaps -> ``[B,K,C,Z]``, bit-identical to
+    :func:`gather_zcolumns` on the volume :func:`unproject_root` writes
+    (``tempo_detector.py:204-206``), without that volume.  ``maps``: the repacked
+    ``[B,V,H,W,CP]`` tensor (``channels`` = real channels), a :class:`MapLayout` of
+    channel-last tensors in place, or the reference's list of V NCHW ``[B,C_total,H,W]``
+    tensors (channels ``[c_begin, c_begin + channels)``)."""
+    lib = _lib.load()
+    if isinstance(maps, MapLayout):
+        dev, B, V, H, W = maps.device, maps.F, maps.V, maps.H, maps.W
+        if channels is None:
+            raise ValueError('channels is required with a MapLayout')
+        C = int(channels)
+        CP = padded_channels(C)
+        ax, batched, (X, Y, Z), K, C, out = _columns_common(cam, axes, index, B, V, C, live,
+                                                            out, dev)
+        head = (maps.ptrs, maps.frame_bytes, maps.texel_bytes)
+        fn, name = lib.tempo_unproject_root_columns_views, 'tempo_unproject_root_columns_views'
+    elif isinstance(maps, torch.Tensor):
+        dev = maps.device
+        _need(maps, torch.float32, 'hm')
+        B, V, H, W, CP = (int(v) for v in maps.shape)
+        if channels is None:
+            raise ValueError('channels is required with a repacked tensor')
+        ax, batched, (X, Y, Z), K, C, out = _columns_common(cam, axes, index, B, V, channels,
+                                                            live, out, dev)
+        if padded_channels(C) != CP:
+            raise ValueError('hm.shape[-1] must be padded_channels(channels)')
+        head = (_ptr(maps),)
+        fn, name = lib.tempo_unproject_root_columns, 'tempo_unproject_root_columns'
+    else:
+        fm0 = maps[0]
+        dev = fm0.device
+        B, C_total, H, W = (int(v) for v in fm0.shape)
+        V = len(maps)
+        C = C_total - c_begin if channels is None else int(channels)
+        CP = padded_channels(C)
+        keep = []
+        for i, fm in enumerate(maps):
+            if tuple(fm.shape) != (B, C_total, H, W):
+                raise ValueError('feature maps of all views must share one shape')
+            if fm.dtype != torch.float32:
+                fm = fm.float()
+            keep.append(_need(fm.contiguous(), torch.float32, f'feature_maps[{i}]', dev))
+        ax, batched, (X, Y, Z), K, C, out = _columns_common(cam, axes, index, B, V, C, live,
+                                                            out, dev)
+        ptrs = (ctypes.c_void_p * V)(*[fm.data_ptr() for fm in keep])
+        head = (ptrs, C_total, int(c_begin))
+        fn, name = lib.tempo_root_step_columns, 'tempo_root_step_columns'
+    with torch.cuda.device(dev):
+        rc = fn(*head, _ptr(cam), _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), int(batched),
+                _ptr(live), _ptr(index), _ptr(out), B, K, V, C, CP, H, W, X, Y, Z,
+                float(heatmap_size[0]), float(heatmap_size[1]), float(image_size[0]),
+                float(image_size[1]), numerics.abi_flag(mm_mode), _stream_ptr(dev))
+    _lib.check(rc, name)
+    return out
+
+
 def conv1x1_nhwc(x, weight, bias, num_views, timesteps=1, out=None):
     """The 2-D head's 1x1 convolution (``rnn_multiview_pose.py:61-66, :321``) writing the
     unprojection's channel-last layout directly.
@@ -893,6 +1032,7 @@ def conv1x1_nhwc(x, weight, bias, num_views, timesteps=1, out=None):
     :func:`repack_nhwc` would produce from ``feature_maps[t]``)."""
     lib = _lib.load()
     dev = x.device
+    _no_grad_path('conv1x1_nhwc', x, weight, bias)
     _need(x, torch.float32, 'x')
     M, K, H, W = (int(v) for v in x.shape)
     V, T = int(num_views), int(timesteps)

@@ -50,17 +50,36 @@ def zslab_range(Z, rank, world):
     return rank * step, (rank + 1) * step
 
 
+def allgather_slabs(local, group=None, out=None):
+    """The collective alone: z-slabs ``[B,C,X,Y,Zr]`` (same shape on every rank) ->
+    ``[R,B,C,X,Y,Zr]`` on every rank (ONE ``all_gather_into_tensor``)."""
+    world = dist.get_world_size(group)
+    local = local.contiguous()
+    if out is None:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out.view(-1), local.view(-1), group=group)
+    return out
+
+
+def assemble_z_slabs(slabs, out=None):
+    """``[R,B,C,X,Y,Zr]`` -> ``[B,C,X,Y,R*Zr]``: z is the fastest axis of the volume, so the
+    rank index moves inside the row.  One HIP kernel on the device (``tempo_assemble_zslabs``);
+    CPU tensors (the gloo tests) go through the equivalent torch permute."""
+    if slabs.is_cuda and slabs.dtype == torch.float32:
+        from . import ops
+        return ops.assemble_zslabs(slabs.contiguous(), out)
+    R, B, C, X, Y, Zr = slabs.shape
+    res = slabs.permute(1, 2, 3, 4, 0, 5).reshape(B, C, X, Y, R * Zr)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
 def gather_z_slabs(local, group=None):
     """All-gather z-slabs ``[B,C,X,Y,Zr]`` (same shape on every rank) into the
     full ``[B,C,X,Y,Zr*R]`` volume, on every rank."""
-    world = dist.get_world_size(group)
-    local = local.contiguous()
-    B, C, X, Y, Zr = local.shape
-    buf = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(buf, local.view(-1), group=group)
-    # [R,B,C,X,Y,Zr] -> [B,C,X,Y,R,Zr] -> [B,C,X,Y,Z]
-    return buf.view(world, B, C, X, Y, Zr).permute(1, 2, 3, 4, 0, 5).reshape(
-        B, C, X, Y, world * Zr)
+    return assemble_z_slabs(allgather_slabs(local, group))
 
 
 def unproject_root_zslab(layer, feature_maps, grid_size, grid_center, cube_size,

@@ -120,10 +120,26 @@ def _check_inputs(feature_maps):
     return fm0.device
 
 
-def _wants_grad(feature_maps):
-    if isinstance(feature_maps, PackedHeatmaps):
+def _requires_grad(feature_maps):
+    """autograd is recording and some input map asks for a gradient"""
+    if not torch.is_grad_enabled():
         return False
-    return torch.is_grad_enabled() and any(fm.requires_grad for fm in feature_maps)
+    if isinstance(feature_maps, PackedHeatmaps):
+        return bool(feature_maps.hm.requires_grad)
+    return any(fm.requires_grad for fm in feature_maps)
+
+
+def _wants_grad(feature_maps):
+    """True when the call must go through the differentiable path.  Packed maps have none
+    (the backward writes per-view NCHW gradients): asking for one raises instead of
+    silently returning a volume that is cut off from the graph."""
+    if isinstance(feature_maps, PackedHeatmaps):
+        if _requires_grad(feature_maps):
+            raise NotImplementedError(
+                'PackedHeatmaps carry no gradient: pass the per-view [B,C,H,W] tensors '
+                '(e.g. list(packed)) for a training step, or call under torch.no_grad()')
+        return False
+    return _requires_grad(feature_maps)
 
 
 def _batch_channels(feature_maps):
@@ -416,6 +432,82 @@ class ProjectLayer(nn.Module):
                 scales, cameras):
         return self.get_voxel(feature_maps, grid_size, grid_center, cube_size,
                               centers, scales, cameras)
+
+    def _consumer_inputs(self, feature_maps, grid_size, grid_center, cube_size, centers, scales,
+                         cameras, what):
+        if _requires_grad(feature_maps):
+            raise NotImplementedError(
+                f'{what} is forward-only (no gradient reaches the feature maps through it); '
+                'use forward() + the torch ops for training')
+        device = _check_inputs(feature_maps)
+        B, C = _batch_channels(feature_maps)
+        live = self._live(grid_center, B, device)
+        axes, cube_size = self._axes(grid_size, grid_center, cube_size, B, device)
+        cam = to_device(pack_cameras(centers, scales, cameras, self.image_size, self.mm_mode),
+                        device)
+        return device, B, C, live, axes, cube_size, cam
+
+    def forward_zmax(self, feature_maps, grid_size, grid_center, cube_size, centers, scales,
+                     cameras):
+        """Extension: ``torch.max(forward(...)[0], dim=4)[0]`` -- the first
+        thing the root detector computes from the volume (``center_net.py:230``) -- without
+        the volume: ``[B,C,X,Y]``, bit-identical, 246 MB of stores fewer at the Panoptic
+        batch.  Arguments as :meth:`forward`.  The volume's only other consumer, the K
+        z-columns of ``tempo_detector.py:204-206``, comes from :meth:`zcolumns`."""
+        device, B, C, live, axes, cube_size, cam = self._consumer_inputs(
+            feature_maps, grid_size, grid_center, cube_size, centers, scales, cameras,
+            'forward_zmax')
+        zmax = torch.empty(B, C, cube_size[0], cube_size[1], dtype=torch.float32, device=device)
+        source = _map_source(feature_maps)
+        for c0, cs in _Slices(C).items:
+            zs = zmax if cs == C else torch.empty(B, cs, *zmax.shape[2:], dtype=torch.float32,
+                                                  device=device)
+            kw = dict(live=live, mm_mode=self.mm_mode, zmax_out=zs, want_cubes=False)
+            if source == 'packed':  # (at most 32 channels: one slice)
+                ops.unproject_root(feature_maps.hm, cam, axes, cs, self.heatmap_size,
+                                   self.image_size, **kw)
+            elif source == 'views':
+                ops.unproject_root_views(ops.channels_last_layout(list(feature_maps), c0), cam,
+                                         axes, cs, self.heatmap_size, self.image_size, **kw)
+            else:
+                ops.root_step(feature_maps, cam, axes, self.heatmap_size, self.image_size, c0,
+                              cs, **kw)
+            if cs != C:
+                zmax[:, c0:c0 + cs] = zs
+        return zmax
+
+    def zcolumns(self, feature_maps, grid_size, grid_center, cube_size, centers, scales,
+                 cameras, index):
+        """Extension: the z-columns of the volume at the cells ``index``
+        int64 ``[B,K]`` (cell = x * Y + y, the detector's ``topk_2d_flatten_index``) ->
+        ``[B,K,C,Z]`` = ``torch.gather(torch.flatten(cubes, 2, 3).permute(0, 2, 1, 3), 1,
+        index[..., None, None].repeat(1, 1, C, Z))`` of ``tempo_detector.py:204-206``,
+        computed from the heatmaps (only those K * Z voxels are unprojected): bit-identical
+        to gathering from :meth:`forward`'s volume, which need not exist."""
+        device, B, C, live, axes, cube_size, cam = self._consumer_inputs(
+            feature_maps, grid_size, grid_center, cube_size, centers, scales, cameras,
+            'zcolumns')
+        index = index.to(device=device, dtype=torch.int64).contiguous()
+        K = int(index.shape[1])
+        out = torch.empty(B, K, C, cube_size[2], dtype=torch.float32, device=device)
+        source = _map_source(feature_maps)
+        for c0, cs in _Slices(C).items:
+            dst = out if cs == C else None
+            kw = dict(channels=cs, live=live, out=dst, mm_mode=self.mm_mode)
+            if source == 'packed':
+                got = ops.unproject_root_columns(feature_maps.hm, cam, axes, index,
+                                                 self.heatmap_size, self.image_size, **kw)
+            elif source == 'views':
+                got = ops.unproject_root_columns(
+                    ops.channels_last_layout(list(feature_maps), c0), cam, axes, index,
+                    self.heatmap_size, self.image_size, **kw)
+            else:
+                got = ops.unproject_root_columns(list(feature_maps), cam, axes, index,
+                                                 self.heatmap_size, self.image_size,
+                                                 c_begin=c0, **kw)
+            if cs != C:
+                out[:, :, c0:c0 + cs] = got
+        return out
 
     def forward_sequence(self, feature_maps_t, grid_size, grid_center_t, cube_size,
                          centers_t, scales_t, cameras_t):

@@ -159,3 +159,38 @@ def test_fused_consumer_entry_points_reject_bad_arguments():
         2, 2, 5, 15, 16, 8, 8, 9, 9, 9, 4, 4, 4, 8.0, 8.0, 32.0, 32.0, 0, None)
     assert planes(v=None) == -1
     assert planes(pxy=None) == -1     # neither the volume nor a plane asked for
+
+
+def test_volume_free_root_entry_points_reject_bad_arguments():
+    """cubes may be NULL only together with the z-max planes; the z-column entry points
+    refuse missing inputs / outputs and bad sizes before anything touches the GPU."""
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    one = P(16)
+    ptrs = (ctypes.c_void_p * 5)(*([16] * 5))
+    zmax = lambda cubes, z: lib.tempo_unproject_root_zmax(
+        one, one, one, one, one, 0, None, cubes, None, None, 0, 2, 5, 15, 16, 8, 8, 4, 4, 4,
+        8.0, 8.0, 32.0, 32.0, 0, z, None)
+    assert zmax(None, None) == -1 and zmax(one, None) == -1
+    step = lambda cubes, z: lib.tempo_root_step_zmax(
+        ptrs, 15, 0, one, one, one, one, 0, None, cubes, None, None, 0, 2, 5, 15, 16, 8, 8, 4, 4,
+        4, 8.0, 8.0, 32.0, 32.0, 0, z, one, 2, None)
+    assert step(None, None) == -1
+    plain = lib.tempo_root_step(ptrs, 15, 0, one, one, one, one, 0, None, None, None, None, 0, 2,
+                                5, 15, 16, 8, 8, 4, 4, 4, 8.0, 8.0, 32.0, 32.0, 0, one, 2, None)
+    assert plain == -1                # no volume and no z-max: nothing to compute
+    cols = lambda **kw: lib.tempo_unproject_root_columns(
+        kw.get('hm', one), one, one, one, one, 0, None, kw.get('index', one), kw.get('out', one),
+        2, kw.get('K', 3), 5, 15, kw.get('CP', 16), 8, 8, 4, 4, 4, 8.0, 8.0, 32.0, 32.0,
+        kw.get('mm', 0), None)
+    assert cols(hm=None) == -1 and cols(index=None) == -1 and cols(out=None) == -1
+    assert cols(K=0) == -2 and cols(CP=18) == -3 and cols(mm=3) == -5
+    assert cols(hm=P(20)) == -5       # the repacked buffer is read with 128-bit loads
+    colv = lambda v=ptrs, tb=64: lib.tempo_unproject_root_columns_views(
+        v, 8 * 8 * 64, tb, one, one, one, one, 0, None, one, one, 2, 3, 5, 15, 16, 8, 8, 4, 4,
+        4, 8.0, 8.0, 32.0, 32.0, 0, None)
+    assert colv(v=None) == -1 and colv(tb=56) == -5   # texels narrower than the C channels
+    coln = lambda v=ptrs, ct=15, c0=0: lib.tempo_root_step_columns(
+        v, ct, c0, one, one, one, one, 0, None, one, one, 2, 3, 5, 15, 16, 8, 8, 4, 4, 4, 8.0,
+        8.0, 32.0, 32.0, 0, None)
+    assert coln(v=None) == -1 and coln(ct=14) == -2 and coln(ct=16, c0=2) == -2
