@@ -304,7 +304,8 @@ class WindowWorkload:
         from tempo_amd import ops, project_layer as PL, synthetic as S
         self.ops = ops
         self.dev = dev
-        self.cfg, self.fms, self.cam, _ = make_inputs(args, dev, seed, getattr(S, self.cfg_src))
+        self.cfg, self.fms, self.cam, self.cam_host = make_inputs(args, dev, seed,
+                                                                  getattr(S, self.cfg_src))
         self.meta = make_inputs.meta
         cfg = self.cfg
         self.B, self.V, self.J = args.batch, cfg['num_views'], cfg['num_joints']
@@ -326,6 +327,7 @@ class WindowWorkload:
         layer._ensure_grids(dev)
         self.geo = [t.to(torch.int32).contiguous() for t in (tl, st, en)]
         self.fine = layer._fine_axes
+        self.fine_host = layer._fine_axes_host
         self.sub = layer._sub_cube
         i = torch.arange(self.NW, device=dev, dtype=torch.int32)
         self.win_frame = ((i // (P * T)) * T + i % T).to(torch.int32).contiguous()
@@ -1009,6 +1011,10 @@ def main():
         gout = torch.rand(wl.out.shape, device=dev)
         grads = [torch.zeros_like(f) for f in wl.fms]
 
+        # the window backward's LDS tile, chosen like the drop-in module does (lattice pitch)
+        tile = 0 if root else ops.backward_tile_texels(
+            wl.cam_host, wl.fine_host, wl.cfg['heatmap_size'], wl.cfg['image_size'])
+
         def fwd():
             if root:
                 ops.unproject_root(wl.hm, wl.cam, wl.axes, wl.J, wl.cfg['heatmap_size'],
@@ -1026,7 +1032,8 @@ def main():
             tl, st, en = wl.geo
             return ops.unproject_window_backward(gout, wl.cam, wl.fine, tl, st, en, cmask,
                                                  wl.hm.shape, wl.cfg['heatmap_size'],
-                                                 wl.cfg['image_size'], win_frame=wl.win_frame)
+                                                 wl.cfg['image_size'], win_frame=wl.win_frame,
+                                                 tile_texels=tile)
 
         def timed(fn, n=10):
             for _ in range(2):
@@ -1044,7 +1051,8 @@ def main():
         u_ms, _ = timed(lambda: ops.unrepack_nchw(ghm, wl.J, out=grads))
         train = {'forward_with_mask_ms': round(f_ms, 4), 'backward_ms': round(b_ms, 4),
                  'unrepack_ms': round(u_ms, 4),
-                 'backward_gsamp_s': round(wl.samples / (b_ms * 1e-3) / 1e9, 3)}
+                 'backward_gsamp_s': round(wl.samples / (b_ms * 1e-3) / 1e9, 3),
+                 'backward_tile_texels': tile}
         del gout, grads, ghm, cmask
 
     if rank == 0:

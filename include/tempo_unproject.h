@@ -127,13 +127,16 @@ int tempo_unproject_root_zmax(const float* hm, const float* cam, const float* ax
                               float* zmax, void* stream);
 
 /* Whole root step for a batch, NCHW maps in, volume out: tempo_repack_nhwc +
- * tempo_unproject_root over chunks of `chunk` frames that reuse ONE channel-last
- * buffer (`workspace`): choose chunk so that a chunk's maps take <= ~100 MB (8
- * frames at the Panoptic sizes) and they stay in the MI355X's 256 MB Infinity
- * Cache between the repack that writes them and the gather that reads them.
+ * tempo_unproject_root over chunks of `chunk` frames through a small channel-last
+ * `workspace`: choose chunk so that a chunk's maps take <= ~190 MB (16 frames at the
+ * Panoptic sizes) and they stay in the MI355X's 256 MB Infinity Cache between the repack
+ * that writes them and the gather that reads them.  A batch of more than one chunk uses the
+ * workspace as two halves: the repack of chunk c + 1 runs as the last workgroups of the
+ * launch that unprojects chunk c (it fills that launch's tail instead of paying its own).
  * Results are those of the two separate calls on the whole batch.
  *   views     : HOST array of V device pointers, fp32 [B, C_total, H, W]
  *   workspace : device fp32 [tempo_root_step_workspace(B, V, H, W, CP, chunk)]
+ *               (= min(B, chunk) frames' maps, twice that when B > chunk)
  *   cam, ax_*, live, cubes, grids, mask : as tempo_unproject_root, for all B items */
 long long tempo_root_step_workspace(int B, int V, int H, int W, int CP, int chunk);
 int tempo_root_step(const void* const* views, int C_total, int c_begin,
@@ -371,7 +374,10 @@ int tempo_unproject_window_train(const float* hm, const float* cam,
  * taller than 16384 texels) keeps the per-view footprints of a tile in LDS, 11
  * views per launch at CP = 16 (10 at 20, 9 at 24, 8 at 28, 7 at 32); more views go
  * through in several launches on `stream`.  The default window backward keeps no
- * per-view records. */
+ * per-view records; it sums the footprints of a 4x4x4 brick of voxels in an LDS tile of
+ * tile_texels texels before they go to memory: 0 (= 121, for lattices up to about two
+ * heatmap pixels per voxel), 121 or 144 (coarser lattices, e.g. H36M windows on 384 x 384
+ * maps at 2.8 pixels per voxel); a speed choice only, TEMPO_E_ARG for other values. */
 int tempo_unproject_root_backward(const float* grad_cubes, const float* cam,
                                   const float* ax_x, const float* ax_y,
                                   const float* ax_z, int ax_batched,
@@ -389,7 +395,7 @@ int tempo_unproject_window_backward(const float* grad_cubes, const float* cam,
                                     int NW, int F, int V, int C, int CP, int H, int W,
                                     int FX, int FY, int FZ, int VX, int VY, int VZ,
                                     float hm_w, float hm_h, float img_w, float img_h,
-                                    int mm_unfused, void* stream);
+                                    int mm_unfused, int tile_texels, void* stream);
 
 /* Inverse of tempo_repack_nhwc: channel-last [B, V, H, W, CP] -> channels
  * [c_begin, c_begin + C) of V per-view fp32 [B, C_total, H, W] tensors

@@ -41,7 +41,7 @@ SIGNATURES = {
     'tempo_unproject_root_backward': (_c_int, [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 3 +
                                       [_c_int] * 9 + [_c_float] * 4 + [_c_int, _c_void_p]),
     'tempo_unproject_window_backward': (_c_int, [_c_void_p] * 12 + [_c_int] * 13 +
-                                        [_c_float] * 4 + [_c_int, _c_void_p]),
+                                        [_c_float] * 4 + [_c_int, _c_int, _c_void_p]),
     'tempo_unrepack_nchw': (_c_int, [_c_void_p, ctypes.POINTER(_c_void_p)] + [_c_int] * 8 +
                             [_c_void_p]),
     'tempo_root_step_workspace': (ctypes.c_longlong, [_c_int] * 6),

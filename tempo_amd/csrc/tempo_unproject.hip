@@ -103,6 +103,8 @@ struct UnprojArgs {
   unsigned view_bytes;     // H*W*CP*4
   int NB;                  // batch items (root) / windows
   int V, C, CP, H, W;
+  int Cs;  // channels per item of the OUTPUT tensors (== C, or the full count when this
+           // launch computes one 16-channel group of a 32-channel call: forward kernels only)
   int dim[3];   // output voxels per axis
   int fdim[3];  // window: extent of the fine axes
   int F;        // frames in hm / cam
@@ -269,7 +271,7 @@ __device__ __forceinline__ void zmax_clear_columns(const UnprojArgs& a, int b, i
     if (c < cols && nc < a.N) {
       int j0, j1, j2;
       voxel_index(a, nc, &j0, &j1, &j2);
-      a.pl01[(((long long)b * a.C + ch) * a.dim[0] + j0) * a.dim[1] + j1] = 0u;
+      a.pl01[(((long long)b * a.Cs + ch) * a.dim[0] + j0) * a.dim[1] + j1] = 0u;
     }
   }
 }
@@ -311,12 +313,12 @@ __device__ __forceinline__ void planes_epilogue(const UnprojArgs& a, int b, int 
         }
         int j0, j1, j2;
         voxel_index(a, nc, &j0, &j1, &j2);
-        a.pl01[(((long long)b * a.C + ch) * a.dim[0] + j0) * a.dim[1] + j1] = m;
+        a.pl01[(((long long)b * a.Cs + ch) * a.dim[0] + j0) * a.dim[1] + j1] = m;
       }
     }
     return;
   }
-  const long long bc = (long long)b * a.C;
+  const long long bc = (long long)b * a.Cs;
   // shorter columns (the root grid's 20 planes): the lanes of one column are
   // consecutive, so a segmented shift-and-max leaves the column's maximum in its
   // first lane and only that lane issues the atomic (a column may continue in
@@ -462,9 +464,14 @@ __device__ __forceinline__ bool voxel_world(const UnprojArgs& a, int b, int n,
 // One wave's 64 voxels [n0, n0 + 64) of batch item / window b, all views: leaves
 // the finished tile (normalised, clamped) in the wave's LDS, [4L channels][65]
 // floats at wbase, lane = voxel; writes the optional grids / mask outputs.
-template <int MODE, int L, int SB, int UNF>
+// KEEP: also hand the finished values back in the gather layout -- keep[s * 4 + j] = bit
+// pattern of channel 4 cq + j of voxel s * VPS + vq (lane = vq * L + cq), clamped, -0.0 as
+// +0.0, so that the patterns order like the values with NaN on top (0 for slots that hold no
+// voxel) -- and write the LDS tile only if the volume is asked for (a.cubes).
+template <int MODE, int L, int SB, int UNF, int KEEP = 0>
 __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int frame, int n0,
-                                               int lane, unsigned char* wbase) {
+                                               int lane, unsigned char* wbase,
+                                               unsigned* keep = nullptr) {
   constexpr int VPS = 64 / L;                       // voxels per sub-step of phase B
   constexpr int NSUB = (kWaveVox + VPS - 1) / VPS;  // sub-steps per wave
   // wave-private LDS: 2 x 64 records of (4 texel offsets, 4 weights): the view
@@ -683,28 +690,33 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
   float* s_out = reinterpret_cast<float*>(wbase);  // [4L][TSTR] floats <= 64*64 bytes for L <= 15
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
-  // the denominator belongs to the voxel: one IEEE reciprocal per voxel in the
-  // phase A layout, handed to the voxel's L channel lanes through LDS
-  {
-    reinterpret_cast<DenRec*>(wbase)[lane] =
-        make_den((MODE != MODE_WINDOW ? (float)cnt : (float)a.V) + 1e-6f);
+  DenRec dr[NSUB];
+  if (MODE == MODE_WINDOW) {
+    // every voxel of a window divides by V + 1e-6 (project_layer.py:367-371): one record,
+    // computed once on scalar-uniform values, instead of one per voxel handed over in LDS
+    const DenRec d = make_den((float)a.V + 1e-6f);
+#pragma unroll
+    for (int s = 0; s < NSUB; s++) dr[s] = d;
+  } else {
+    // the denominator belongs to the voxel: one IEEE reciprocal per voxel in the
+    // phase A layout, handed to the voxel's L channel lanes through LDS
+    reinterpret_cast<DenRec*>(wbase)[lane] = make_den((float)cnt + 1e-6f);
     if (MODE == MODE_ROOT && a.mask != nullptr && lane < a.wave_vox && n < a.N) {
       char* m = (char*)a.mask + ((long long)b * a.N + n) * a.mask_bytes;
       if (a.mask_bytes == 1) *(uint8_t*)m = (uint8_t)mbits;
       else if (a.mask_bytes == 2) *(uint16_t*)m = (uint16_t)mbits;
       else *(uint32_t*)m = mbits;
     }
-  }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  DenRec dr[NSUB];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int s = 0; s < NSUB; s++) {
-    const int vsl = s * VPS + vq;
-    dr[s] = reinterpret_cast<const DenRec*>(wbase)[(lane_on && vsl < kWaveVox) ? vsl : 0];
+    for (int s = 0; s < NSUB; s++) {
+      const int vsl = s * VPS + vq;
+      dr[s] = reinterpret_cast<const DenRec*>(wbase)[(lane_on && vsl < kWaveVox) ? vsl : 0];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
   // exact division; a NaN anywhere in the wave (torch.clamp keeps it) sends the whole
   // wave through the NaN-aware clamp
   const bool slow = normalise_tile<NSUB>(acc01, acc23, dr);
@@ -723,6 +735,30 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
         if (lane == 0) mw[s * 4 + j] = bal;
       }
     }
+  }
+  if (KEEP) {
+#pragma unroll
+    for (int s = 0; s < NSUB; s++) {
+      const bool live_el = lane_on && s * VPS + vq < kWaveVox;
+      const float e[4] = {acc01[s].x, acc01[s].y, acc23[s].x, acc23[s].y};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        unsigned bits;
+        if (!slow) {
+          // clamp to [0, 1] on the bit pattern (one v_med3_i32): every negative value,
+          // -0.0 included, has a negative pattern and becomes +0.0; no NaN in this wave
+          int t = (int)__float_as_uint(e[j]);
+          t = t < 0 ? 0 : t;
+          t = t > 0x3f800000 ? 0x3f800000 : t;
+          bits = (unsigned)t;
+        } else {
+          const float v = tempo_nan_clamp(e[j], 0.0f, 1.0f);
+          bits = v == 0.0f ? 0u : __float_as_uint(v);
+        }
+        keep[s * 4 + j] = live_el ? bits : 0u;
+      }
+    }
+    if (a.cubes == nullptr) return;  // (wave-uniform) nobody reads the tile
   }
 #pragma unroll
   for (int s = 0; s < NSUB; s++) {
@@ -799,7 +835,7 @@ __device__ __forceinline__ void unproject_block(const UnprojArgs& a, int bid,
   if (dead) {
     if (lane < a.wave_vox && n < a.N) {
       if (a.cubes != nullptr)
-        for (int ch = 0; ch < a.C; ch++) a.cubes[((long long)b * a.C + ch) * a.N + n] = 0.0f;
+        for (int ch = 0; ch < a.C; ch++) a.cubes[((long long)b * a.Cs + ch) * a.N + n] = 0.0f;
       if (a.grids != nullptr) {
         float* g = a.grids + ((long long)b * a.N + n) * 3;
         g[0] = g[1] = g[2] = 0.0f;
@@ -821,7 +857,7 @@ __device__ __forceinline__ void unproject_block(const UnprojArgs& a, int bid,
 #if defined(TEMPO_ABLATE) && TEMPO_ABLATE == 2  // (almost) no stores
     if (s_out[lane] == 123.456f)
 #endif
-    store_tile(a.cubes + (long long)b * a.C * a.N, a.C, a.N, n, s_out + lane, TSTR);
+    store_tile(a.cubes + (long long)b * a.Cs * a.N, a.C, a.N, n, s_out + lane, TSTR);
   }
   if (a.pl01 != nullptr || a.pl02 != nullptr || a.pl12 != nullptr)
     planes_epilogue(a, b, n0, lane, s_out, TSTR);
@@ -921,16 +957,32 @@ __global__ __launch_bounds__(kTileWaves * 64) void unproject_columns_kernel(cons
 constexpr int kPlaneXR = TEMPO_PL_XR;  // columns a wave walks along x
 constexpr int kPlaneWaves = TEMPO_PL_WAVES;
 constexpr int kPlaneXB = TEMPO_PL_XB;
+constexpr int kAccStr = kWaveVox + 2;  // row stride of the y-max accumulators (words)
 constexpr int plane_lds_bytes(int L) {
-  return kPlaneWaves * wave_lds_bytes(L) + kPlaneXB * 4 * L * kWaveVox * 4;
+  // the waves' record / tile regions, the y-max accumulators, 32 z-max words per wave
+  return kPlaneWaves * wave_lds_bytes(L) + kPlaneXB * 4 * L * kAccStr * 4 + kPlaneWaves * 128;
 }
 
+// Epilogue in registers (CP = 16; 32-channel calls come in as two 16-channel launches,
+// launch_forward): the finished values stay in the gather layout (unproject_wave<KEEP>) -- lane =
+// (voxel vq, channel quad cq), slot (s, j) = channel 4 cq + j of voxel z = s * VPS + vq -- and
+//   max over x  is 4 NSUB running maxima per lane,
+//   max over y  one ds_max_u32 per slot into the workgroup's accumulators (same layout),
+//   max over z  the maximum over a lane's sub-steps, over the lanes of its 16-lane row that
+//               hold the same quad (two DPP rotations), then one ds_max_u32 per row into
+//               16 words of the wave's LDS,
+// and the LDS tile is written only when the volume is stored.  Against the tile form (every
+// value through LDS twice, -0.0 patched on every read: 165 VALU + 64 LDS instructions per
+// column on top of the tile kernel's 1141 + 78) this is ~60 VALU + 21 LDS.
 template <int L, int UNF>
-__global__ __launch_bounds__(kPlaneWaves * 64) void unproject_planes_kernel(
-    const UnprojArgs a) {
+__global__ __launch_bounds__(kPlaneWaves * 64) void unproject_planes_kernel(const UnprojArgs a) {
   constexpr int SB = TEMPO_PL_SB;  // two sub-steps of fetches in flight (fewer waves fit here)
   constexpr int CH = 4 * L;
   constexpr int TSTR = kWaveVox + 1;
+  constexpr bool REG = L == 4;
+  constexpr int VPS = 64 / L;
+  constexpr int NSUB = (kWaveVox + VPS - 1) / VPS;
+  constexpr int SL = REG ? 4 * NSUB : CH;  // accumulator rows per column (== CH for L = 4, 8)
   extern __shared__ __align__(16) unsigned char smem[];
   const int bid = blockIdx.x;
   const int run = bid >> 3;
@@ -947,10 +999,14 @@ __global__ __launch_bounds__(kPlaneWaves * 64) void unproject_planes_kernel(
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int y = (rem - xb * yblocks) * kPlaneWaves + wave;
-  const int x_begin = xb * kPlaneXR;
-  const int x_end = x_begin + kPlaneXR < VX ? x_begin + kPlaneXR : VX;
+  // The walk of x-block xb visits x = xb, xb + xblocks, xb + 2 xblocks, ...: the workgroups
+  // of a window (resident on one XCD together) are at neighbouring x at any time, a slab of
+  // the window a few columns thick, rather than spread over its whole depth (4.147 against
+  // 4.175 ms at config 3 for x-block xb walking xb * kPlaneXR + step)
+  const int x_begin = xb, x_step = xblocks, x_end = VX;
   unsigned char* wbase = smem + (size_t)wave * wave_lds_bytes(L);
   unsigned* acc = reinterpret_cast<unsigned*>(smem + (size_t)kPlaneWaves * wave_lds_bytes(L));
+  unsigned* zacc = acc + kPlaneXB * CH * kAccStr + wave * 32;  // [CH <= 32] per wave
 
   int frame = b;
   if (a.win_frame != nullptr) frame = uniform_load(a.win_frame, b);
@@ -958,83 +1014,148 @@ __global__ __launch_bounds__(kPlaneWaves * 64) void unproject_planes_kernel(
                     (unsigned)frame >= (unsigned)a.F;
   if (dead) {  // the planes were cleared by the host; the volume is zero-filled here
     if (a.cubes != nullptr)
-      for (int x = x_begin; x < x_end; x++)
+      for (int x = x_begin; x < x_end; x += x_step)
         for (int ch = 0; ch < a.C; ch++)
-          a.cubes[((long long)b * a.C + ch) * a.N + (x * VY + y) * kWaveVox + lane] = 0.0f;
+          a.cubes[((long long)b * a.Cs + ch) * a.N + (x * VY + y) * kWaveVox + lane] = 0.0f;
     return;
   }
-  for (int r = wave; r < kPlaneXB * CH; r += kPlaneWaves) acc[r * kWaveVox + lane] = 0u;
+  for (int r = wave; r < kPlaneXB * CH; r += kPlaneWaves) acc[r * kAccStr + lane] = 0u;
+  if (lane < 32) zacc[lane] = 0u;
   __syncthreads();
 
-  const long long bc = (long long)b * a.C;
-  unsigned over_x[CH];
+  const long long bc = (long long)b * a.Cs;
+  unsigned over_x[REG ? SL : CH];
 #pragma unroll
-  for (int ch = 0; ch < CH; ch++) over_x[ch] = 0u;
+  for (int i = 0; i < (REG ? SL : CH); i++) over_x[i] = 0u;
   const float* s_out = reinterpret_cast<const float*>(wbase);
+  // gather layout of this lane (REG)
+  const int vq = lane / L, cq = lane - vq * L;
+  const bool lane_on = lane < VPS * L;
 #pragma unroll 1
-  for (int x = x_begin; x < x_end; x++) {
+  for (int x = x_begin, walk = 0; x < x_end; x += x_step, walk++) {
     const int n0 = (x * VY + y) * kWaveVox;
-    unproject_wave<MODE_WINDOW, L, SB, UNF>(a, b, frame, n0, lane, wbase);
-    if (a.cubes != nullptr)
-      store_tile(a.cubes + (long long)b * a.C * a.N, a.C, a.N, n0 + lane, s_out + lane, TSTR);
-    const int xs = (x - x_begin) % kPlaneXB;
+    const int xs = walk % kPlaneXB;
+    if (REG) {
+      unsigned pv[SL];
+      unproject_wave<MODE_WINDOW, L, SB, UNF, 1>(a, b, frame, n0, lane, wbase, pv);
+      if (a.cubes != nullptr)
+        store_tile(a.cubes + (long long)b * a.Cs * a.N, a.C, a.N, n0 + lane, s_out + lane, TSTR);
+      // the accumulators are [channel][z] rows (kAccStr apart: with 66 the 32 lanes of an
+      // LDS cycle, 8 voxels x 4 quads, fall into 32 different banks), so that the flush reads
+      // them as rows and every global atomic instruction covers 256 contiguous bytes
 #pragma unroll
-    for (int ch = 0; ch < CH; ch++) {
-      if ((ch & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // four rows in flight, not CH
-      unsigned v = __float_as_uint(s_out[ch * TSTR + lane]);
-      v = v == 0x80000000u ? 0u : v;  // -0.0 orders as +0.0
-      over_x[ch] = v > over_x[ch] ? v : over_x[ch];
-      if (v != 0u)
-        __hip_atomic_fetch_max(acc + (xs * CH + ch) * kWaveVox + lane, v, __ATOMIC_RELAXED,
+      for (int i = 0; i < SL; i++) {
+        over_x[i] = pv[i] > over_x[i] ? pv[i] : over_x[i];
+        const int ch = 4 * cq + (i & 3), z = (i >> 2) * VPS + vq;
+        __hip_atomic_fetch_max(acc + (xs * CH + ch) * kAccStr + z, pv[i], __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (a.pl01 != nullptr) {
-      // max over z: four lanes per channel row of the tile, 16 voxels each, then
-      // the quad is combined (16 channels per pass)
+      }
+      if (a.pl01 != nullptr) {
 #pragma unroll
-      for (int c0 = 0; c0 < CH; c0 += 16) {
-        const int ch = c0 + (lane >> 2);
-        const float* row = s_out + (ch < CH ? ch : 0) * TSTR + (lane & 3) * 16;
-        unsigned m = 0u;
+        for (int j = 0; j < 4; j++) {
+          unsigned m = pv[j];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-          if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);
-          unsigned v = __float_as_uint(row[k]);
-          v = v == 0x80000000u ? 0u : v;  // -0.0 orders as +0.0
-          m = v > m ? v : m;
+          for (int s = 1; s < NSUB; s++) m = pv[s * 4 + j] > m ? pv[s * 4 + j] : m;
+          // the lanes of this 16-lane row that hold the same quad are L apart
+          if (L == 4) {
+            unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x124, 0xf, 0xf, true);
+            m = o > m ? o : m;  // row_ror:4
+          }
+          {
+            unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xf, 0xf, true);
+            m = o > m ? o : m;  // row_ror:8
+          }
+          if ((lane & 15) < L)
+            __hip_atomic_fetch_max(zacc + 4 * cq + j, m, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, true);
-        m = o > m ? o : m;  // quad_perm:[1,0,3,2]
-        o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, true);
-        m = o > m ? o : m;  // quad_perm:[2,3,0,1]
-        if ((lane & 3) == 0 && ch < a.C) a.pl01[((bc + ch) * VX + x) * VY + y] = m;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < CH) {
+          const unsigned m = zacc[lane];
+          zacc[lane] = 0u;
+          if (lane < a.C) a.pl01[((bc + lane) * VX + x) * VY + y] = m;
+        }
+      }
+    } else {
+      unproject_wave<MODE_WINDOW, L, SB, UNF>(a, b, frame, n0, lane, wbase);
+      if (a.cubes != nullptr)
+        store_tile(a.cubes + (long long)b * a.Cs * a.N, a.C, a.N, n0 + lane, s_out + lane, TSTR);
+#pragma unroll
+      for (int ch = 0; ch < CH; ch++) {
+        if ((ch & 3) == 0) __builtin_amdgcn_sched_barrier(0);  // four rows in flight, not CH
+        unsigned v = __float_as_uint(s_out[ch * TSTR + lane]);
+        v = v == 0x80000000u ? 0u : v;  // -0.0 orders as +0.0
+        over_x[ch] = v > over_x[ch] ? v : over_x[ch];
+        if (v != 0u)
+          __hip_atomic_fetch_max(acc + (xs * CH + ch) * kAccStr + lane, v, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (a.pl01 != nullptr) {
+        // max over z: four lanes per channel row of the tile, 16 voxels each, then
+        // the quad is combined (16 channels per pass)
+#pragma unroll
+        for (int c0 = 0; c0 < CH; c0 += 16) {
+          const int ch = c0 + (lane >> 2);
+          const float* row = s_out + (ch < CH ? ch : 0) * TSTR + (lane & 3) * 16;
+          unsigned m = 0u;
+#pragma unroll
+          for (int k = 0; k < 16; k++) {
+            if ((k & 3) == 0) __builtin_amdgcn_sched_barrier(0);
+            unsigned v = __float_as_uint(row[k]);
+            v = v == 0x80000000u ? 0u : v;  // -0.0 orders as +0.0
+            m = v > m ? v : m;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xf, 0xf, true);
+          m = o > m ? o : m;  // quad_perm:[1,0,3,2]
+          o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xf, 0xf, true);
+          m = o > m ? o : m;  // quad_perm:[2,3,0,1]
+          if ((lane & 3) == 0 && ch < a.C) a.pl01[((bc + ch) * VX + x) * VY + y] = m;
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (xs == kPlaneXB - 1 || x == x_end - 1) {
+    if (xs == kPlaneXB - 1 || x + x_step >= x_end) {
       __syncthreads();
       for (int r = wave; r < (xs + 1) * CH; r += kPlaneWaves) {
         const int rx = r / CH, ch = r - rx * CH;
-        const unsigned v = acc[r * kWaveVox + lane];
-        acc[r * kWaveVox + lane] = 0u;
+        const unsigned v = acc[r * kAccStr + lane];
+        acc[r * kAccStr + lane] = 0u;
         if (v != 0u && ch < a.C && a.pl02 != nullptr)
-          __hip_atomic_fetch_max(a.pl02 + ((bc + ch) * VX + (x - xs + rx)) * kWaveVox + lane,
-                                 v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_max(
+              a.pl02 + ((bc + ch) * VX + (x - (xs - rx) * x_step)) * kWaveVox + lane, v,
+              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
     }
   }
   if (a.pl12 != nullptr) {
+    if (REG) {  // gather layout -> [channel][z] rows through the wave's (now idle) LDS region
+      unsigned* t = reinterpret_cast<unsigned*>(wbase);
 #pragma unroll
-    for (int ch = 0; ch < CH; ch++) {
-      if (ch >= a.C) continue;
+      for (int i = 0; i < SL; i++) {
+        const int z = (i >> 2) * VPS + vq;
+        if (lane_on && z < kWaveVox) t[(4 * cq + (i & 3)) * TSTR + z] = over_x[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    auto put = [&](int ch, unsigned v) {
       unsigned* dst = a.pl12 + ((bc + ch) * VY + y) * kWaveVox + lane;
-      if (xblocks == 1) *dst = over_x[ch];  // this wave owns (window, y) entirely
-      else if (over_x[ch] != 0u)
-        __hip_atomic_fetch_max(dst, over_x[ch], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (xblocks == 1) *dst = v;  // this wave owns (window, y) entirely
+      else if (v != 0u)
+        __hip_atomic_fetch_max(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (REG) {
+      for (int ch = 0; ch < a.C; ch++)
+        put(ch, reinterpret_cast<const unsigned*>(wbase)[ch * TSTR + lane]);
+    } else {
+#pragma unroll
+      for (int ch = 0; ch < CH; ch++)
+        if (ch < a.C) put(ch, over_x[ch]);
     }
   }
 }
@@ -1477,31 +1598,30 @@ __global__ __launch_bounds__(kThreads) void unproject_backward_kernel(const Unpr
 // 64 texels 22.9 / -, 81 20.7 / 5.96, 100 19.7 / 5.39, 121 19.8 / 5.00, 144 21.1 / 4.67 --
 // a brick whose box does not fit is done as two halves, which costs more than the waves
 // the larger tile displaces (12 instead of 16 per CU), up to about 1.5x the mean box.
-#ifndef TEMPO_BRICK_CAP
-#define TEMPO_BRICK_CAP 121
-#endif
-constexpr int kBrickCap = TEMPO_BRICK_CAP;  // texels per tile
+// The tile size is chosen per launch (tempo_unproject_window_backward's tile_texels): 121
+// texels suit lattices up to about two heatmap pixels per voxel (config 3: 1.5), 144 the
+// coarser ones (H36M windows on 384 x 384 maps: 2.8 pixels per voxel, 5.00 -> 4.67 ms).
+constexpr int kBrickCapSmall = 121, kBrickCapLarge = 144;  // texels per tile
 struct BrickLds {
   int tile, stage, rec, total;
 };
-// CP = 16: 121 * 64 + 16 * 65 * 4 + 64 * 12 = 12672 bytes, 12 waves per CU
-constexpr BrickLds brick_lds(int L) {
+// CP = 16, 121 texels: 121 * 64 + 16 * 65 * 4 + 64 * 12 = 12672 bytes, 12 waves per CU
+constexpr BrickLds brick_lds(int L, int cap) {
   BrickLds l{};
   l.tile = 0;
-  l.stage = kBrickCap * 4 * L * 4;
+  l.stage = cap * 4 * L * 4;
   l.rec = l.stage + 4 * L * (kWaveVox + 1) * 4;
   l.total = l.rec + 3 * kWaveVox * 4;
   return l;
 }
 
-template <int L, int UNF>
+template <int L, int UNF, int CAP>
 __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojArgs a) {
   constexpr int MODE = MODE_WINDOW;
   constexpr int VPS = 64 / L;
   constexpr int CP = 4 * L;
   constexpr int TSTR = kWaveVox + 1;
-  constexpr int CAP = kBrickCap;
-  constexpr BrickLds LD = brick_lds(L);
+  constexpr BrickLds LD = brick_lds(L, CAP);
   extern __shared__ __align__(16) unsigned char smem[];
   float* tile = reinterpret_cast<float*>(smem + LD.tile);  // CAP texels x CP
   float* st = reinterpret_cast<float*>(smem + LD.stage);   // [CP][TSTR]
@@ -1856,6 +1976,37 @@ void launch_repack_wide(const RepackArgs& a, hipStream_t stream) {
   hipLaunchKernelGGL((repack_wide_kernel<L>), grid, dim3(kThreads), 0, stream, a);
 }
 
+// The root tile kernel with the NEXT chunk's repack as its last workgroups (tempo_root_step):
+// workgroups [0, unproj_blocks) unproject chunk c out of one half of the workspace, the
+// rest repack chunk c + 1 into the other half.  Workgroups are dispatched in index order, so
+// the repack starts when the last unprojection workgroups have been handed out and fills the
+// launch's tail (a quarter of the wave slots idle on average over a launch otherwise) instead
+// of paying a ramp and a tail of its own.  No dependency between the two roles inside a
+// launch.  Results are those of the separate launches.
+template <int L, int SB, int UNF>
+__global__ __launch_bounds__(kThreads) void unproject_repack_kernel(const UnprojArgs a,
+                                                                    const RepackArgs r,
+                                                                    int unproj_blocks,
+                                                                    int pix_tiles) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int bid = blockIdx.x;
+  if (bid < unproj_blocks) {
+    unproject_block<MODE_ROOT, L, SB, UNF>(a, bid, smem);
+    return;
+  }
+  const int t = bid - unproj_blocks;
+  const int bx = t % pix_tiles;
+  const int vb = t / pix_tiles;
+  repack_wide_block<L>(r, bx, vb % r.V, vb / r.V, reinterpret_cast<float*>(smem));
+}
+
+constexpr long long kFuseBytes = 220ll << 20;  // both halves of a fused step's workspace
+
+constexpr int fused_lds_bytes(int L) {
+  return kTileWaves * wave_lds_bytes(L) > 4 * L * kWideStr * 4 ? kTileWaves * wave_lds_bytes(L)
+                                                                : 4 * L * kWideStr * 4;
+}
+
 // The inverse with the same tile: 256 * CP * 4 contiguous bytes in (16-byte
 // loads, transposed b32 writes into the channel-major LDS tile), 1 KB runs of one
 // channel plane out.  Same conditions as the wide repack.
@@ -2157,7 +2308,7 @@ __global__ __launch_bounds__(kThreads) void project_points_kernel(
 
 // ------------------------------------------------------------ host helpers
 template <int MODE, int L, int UNF>
-int launch_one(const UnprojArgs& a, hipStream_t stream) {
+int launch_one(const UnprojArgs& a, hipStream_t stream, const RepackArgs* tail = nullptr) {
   // sub-steps whose fetches are in flight together (8 = all of a view's)
   // (wider texels: two sub-steps keep the fetch registers at 32 and the occupancy up;
   // 20 channels 0.38 -> 0.31 ms, 32 channels 0.53 -> 0.49 ms at config 2's shape)
@@ -2207,8 +2358,22 @@ int launch_one(const UnprojArgs& a, hipStream_t stream) {
   if (total > 0x7fffffffLL / 8) return TEMPO_E_DIM;
   k.total = (int)total;
   k.chunk = (k.total + 7) / 8;
+  if (MODE == MODE_ROOT && tail != nullptr && kTileWaves * 64 == kThreads) {
+    // the next chunk's repack rides on this launch (unproject_repack_kernel)
+    const int pix_tiles = (tail->HW + kWidePix - 1) / kWidePix;
+    const long long rb = (long long)pix_tiles * tail->V * tail->B;
+    if (8LL * k.chunk + rb > 0x7fffffffLL) return TEMPO_E_DIM;
+    hipLaunchKernelGGL((unproject_repack_kernel<L, SB, UNF>), dim3((unsigned)(8 * k.chunk + rb)),
+                       dim3(kThreads), (size_t)fused_lds_bytes(L), stream, k, *tail,
+                       8 * k.chunk, pix_tiles);
+    return (int)hipGetLastError();
+  }
+#ifndef TEMPO_TILE_PAD_LDS  // measurement builds: extra LDS per workgroup caps the occupancy
+#define TEMPO_TILE_PAD_LDS 0
+#endif
   hipLaunchKernelGGL((unproject_kernel<MODE, L, SB, UNF>), dim3(8 * k.chunk),
-                     dim3(kTileWaves * 64), (size_t)kTileWaves * wave_lds_bytes(L), stream, k);
+                     dim3(kTileWaves * 64),
+                     (size_t)kTileWaves * wave_lds_bytes(L) + TEMPO_TILE_PAD_LDS, stream, k);
   return (int)hipGetLastError();
 }
 
@@ -2242,7 +2407,7 @@ int launch_backward_one(const UnprojArgs& a, hipStream_t stream) {
 }
 
 // window backward through the LDS tile (window_backward_brick_kernel)
-template <int L, int UNF>
+template <int L, int UNF, int CAP>
 int launch_backward_brick(const UnprojArgs& a, hipStream_t stream) {
   UnprojArgs k = a;
   fill_order_magic(k.order, k.magic, a.V, a.dim);
@@ -2255,21 +2420,26 @@ int launch_backward_brick(const UnprojArgs& a, hipStream_t stream) {
   k.tiles = (int)bricks;
   k.total = (int)total;
   k.chunk = (k.total + 7) / 8;
-  hipLaunchKernelGGL((window_backward_brick_kernel<L, UNF>), dim3(8 * k.chunk), dim3(64),
-                     (size_t)brick_lds(L).total, stream, k);
+  hipLaunchKernelGGL((window_backward_brick_kernel<L, UNF, CAP>), dim3(8 * k.chunk), dim3(64),
+                     (size_t)brick_lds(L, CAP).total, stream, k);
   return (int)hipGetLastError();
 }
 
 template <int MODE>
-int launch_backward(const UnprojArgs& a, int mm_unfused, hipStream_t stream) {
+int launch_backward(const UnprojArgs& a, int mm_unfused, hipStream_t stream, int tile = 0) {
   if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
+  if (tile != 0 && tile != kBrickCapSmall && tile != kBrickCapLarge) return TEMPO_E_ARG;
+  const bool large = tile == kBrickCapLarge;
 #ifndef TEMPO_NO_BRICK
   // the footprint box is kept in 16-bit texel coordinates
   if (MODE == MODE_WINDOW && a.W <= 16384 && a.H <= 16384) {
-#define TEMPO_BRICK_CASE(LL)                                      \
-  case LL:                                                        \
-    return mm_unfused ? launch_backward_brick<LL, 1>(a, stream)   \
-                      : launch_backward_brick<LL, 0>(a, stream);
+#define TEMPO_BRICK_CASE(LL)                                                            \
+  case LL:                                                                              \
+    if (large)                                                                          \
+      return mm_unfused ? launch_backward_brick<LL, 1, kBrickCapLarge>(a, stream)       \
+                        : launch_backward_brick<LL, 0, kBrickCapLarge>(a, stream);      \
+    return mm_unfused ? launch_backward_brick<LL, 1, kBrickCapSmall>(a, stream)         \
+                      : launch_backward_brick<LL, 0, kBrickCapSmall>(a, stream);
     switch (a.CP / 4) {
       TEMPO_BRICK_CASE(4)
       TEMPO_BRICK_CASE(5)
@@ -2297,23 +2467,24 @@ int launch_backward(const UnprojArgs& a, int mm_unfused, hipStream_t stream) {
 }
 
 template <int MODE, int UNF>
-int launch_l(const UnprojArgs& a, hipStream_t stream) {
+int launch_l(const UnprojArgs& a, hipStream_t stream, const RepackArgs* tail) {
   switch (a.CP / 4) {
-    case 4: return launch_one<MODE, 4, UNF>(a, stream);
-    case 5: return launch_one<MODE, 5, UNF>(a, stream);
-    case 6: return launch_one<MODE, 6, UNF>(a, stream);
-    case 7: return launch_one<MODE, 7, UNF>(a, stream);
-    case 8: return launch_one<MODE, 8, UNF>(a, stream);
+    case 4: return launch_one<MODE, 4, UNF>(a, stream, tail);
+    case 5: return launch_one<MODE, 5, UNF>(a, stream, tail);
+    case 6: return launch_one<MODE, 6, UNF>(a, stream, tail);
+    case 7: return launch_one<MODE, 7, UNF>(a, stream, tail);
+    case 8: return launch_one<MODE, 8, UNF>(a, stream, tail);
     default: return TEMPO_E_PAD;
   }
 }
 
 template <int MODE>
-int launch_mode(const UnprojArgs& a, int mm_unfused, hipStream_t stream) {
+int launch_mode(const UnprojArgs& a, int mm_unfused, hipStream_t stream,
+                const RepackArgs* tail = nullptr) {
   // the three matmul sites share one flavour on every host measured so far;
   // mixed flavours are not compiled in
-  if (mm_unfused == 0) return launch_l<MODE, 0>(a, stream);
-  if (mm_unfused == TEMPO_UNFUSED_ALL) return launch_l<MODE, 1>(a, stream);
+  if (mm_unfused == 0) return launch_l<MODE, 0>(a, stream, tail);
+  if (mm_unfused == TEMPO_UNFUSED_ALL) return launch_l<MODE, 1>(a, stream, tail);
   return TEMPO_E_ARG;
 }
 
@@ -2347,6 +2518,51 @@ int launch_columns(const UnprojArgs& a, int mm_unfused, hipStream_t stream) {
 #undef TEMPO_COL_CASE
 }
 
+// The fused window planes of a call whose texels are 32 channels wide, as two launches of 16
+// channels each (the same texels, the second group 64 bytes further on; outputs of group g
+// start 16 g channels further on and keep the full channel count as their stride,
+// UnprojArgs::Cs).  The 32-channel instantiation of the column walk needs 175 VGPRs (2 waves
+// per SIMD) and 66 KB of LDS per workgroup; config 3's shape at 32 channels, planes only:
+// 16.8 ms in one launch, 9.8 ms in two.  Per-voxel results do not depend on the grouping
+// (channels are independent).  The VOLUME kernels stay with one 32-channel launch: a 128-byte
+// texel is exactly one cache line, and two 16-channel launches fetch every line twice
+// (measured: root 0.369 -> 0.631 ms of kernel time per step, window 6.41 -> 8.35 ms).
+template <int MODE>
+int launch_forward(const UnprojArgs& a, int mm_unfused, hipStream_t stream,
+                   const RepackArgs* tail = nullptr) {
+#ifndef TEMPO_NO_CHANNEL_GROUPS
+  const bool planes = a.pl01 != nullptr || a.pl02 != nullptr || a.pl12 != nullptr;
+  if (MODE == MODE_WINDOW && planes && a.CP == 32 && a.dim[2] == kWaveVox &&
+      a.dim[1] % kPlaneWaves == 0 && a.groups == nullptr && a.cmask == nullptr &&
+      a.ghm == nullptr) {
+    for (int g = 0; g < 2; g++) {
+      const int cs = a.C - 16 * g < 16 ? a.C - 16 * g : 16;
+      if (cs <= 0) break;
+      UnprojArgs k = a;
+      k.C = cs;
+      k.CP = 16;
+      for (int v = 0; v < a.V; v++) k.vbase[v] = a.vbase[v] + 64 * g;
+      k.map_bytes = (unsigned)((long long)a.H * a.row_bytes - a.texel_bytes + 4ll * cs);
+      const long long n = a.N;
+      if (k.cubes != nullptr) k.cubes += 16ll * g * n;
+      if (k.pl01 != nullptr) k.pl01 += 16ll * g * a.dim[0] * a.dim[1];
+      if (k.pl02 != nullptr) k.pl02 += 16ll * g * a.dim[0] * a.dim[2];
+      if (k.pl12 != nullptr) k.pl12 += 16ll * g * a.dim[1] * a.dim[2];
+      if (g > 0) {  // the channel-independent outputs come from the first group
+        k.grids = nullptr;
+        k.mask = nullptr;
+        k.mask_bytes = 0;
+      }
+      const bool last = a.C - 16 * (g + 1) <= 0;
+      const int rc = launch_mode<MODE>(k, mm_unfused, stream, last ? tail : nullptr);
+      if (rc != TEMPO_OK) return rc;
+    }
+    return TEMPO_OK;
+  }
+#endif
+  return launch_mode<MODE>(a, mm_unfused, stream, tail);
+}
+
 // 16-byte alignment of a device pointer the kernels access with 128-bit loads / stores
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -2360,9 +2576,11 @@ int check_common(int V, int C, int CP, int H, int W) {
 }
 
 struct Extra {
+  const RepackArgs* tail = nullptr;     // root forward: the next chunk's repack rides along
   float* zmax = nullptr;                // root forward: max over z, [B][C][X][Y]
   unsigned long long* cmask = nullptr;  // forward: record / backward: read the clamp mask
   float* ghm = nullptr;                 // backward: gradient of the heatmaps (accumulated)
+  int tile = 0;                         // window backward: texels per LDS tile (0 = default)
 };
 
 // Where the heatmaps are: `hm` = the repacked [F][V][H][W][CP] buffer (all kernels), or
@@ -2638,11 +2856,14 @@ int tempo_unproject_window_backward(const float* grad_cubes, const float* cam,
                                     float* grad_hm, int NW, int F, int V, int C, int CP, int H,
                                     int W, int FX, int FY, int FZ, int VX, int VY, int VZ,
                                     float hm_w, float hm_h, float img_w, float img_h,
-                                    int mm_unfused, void* stream) {
+                                    int mm_unfused, int tile_texels, void* stream) {
   if (!grad_cubes || !clamp_mask || !grad_hm) return TEMPO_E_NULL;
+  if (tile_texels != 0 && tile_texels != kBrickCapSmall && tile_texels != kBrickCapLarge)
+    return TEMPO_E_ARG;
   Extra ex;
   ex.cmask = reinterpret_cast<unsigned long long*>(const_cast<uint64_t*>(clamp_mask));
   ex.ghm = grad_hm;
+  ex.tile = tile_texels;
   return window_impl(grad_hm, cam, win_frame, fx, fy, fz, tl, start, end, live,
                      const_cast<float*>(grad_cubes), nullptr, nullptr, nullptr, NW, F, V, C, CP,
                      H, W, FX, FY, FZ, VX, VY, VZ, hm_w, hm_h, img_w, img_h, mm_unfused,
@@ -2725,7 +2946,7 @@ int root_impl(const Layout& lay, const float* cam, const float* ax_x, const floa
   a.mask_bytes = mask_bytes;
   a.frame_stride = (long long)V * H * W * CP;
   a.view_bytes = (unsigned)((long long)H * W * CP * 4);
-  a.NB = B; a.F = B; a.V = V; a.C = C; a.CP = CP; a.H = H; a.W = W;
+  a.NB = B; a.F = B; a.V = V; a.C = C; a.Cs = C; a.CP = CP; a.H = H; a.W = W;
   a.dim[0] = X; a.dim[1] = Y; a.dim[2] = Z; a.N = (int)N;
   a.geom = tempo_make_geom(hm_w, hm_h, img_w, img_h);
   a.groups = groups; a.NG = num_groups;
@@ -2749,7 +2970,8 @@ int root_impl(const Layout& lay, const float* cam, const float* ax_x, const floa
     }
     a.pl01 = reinterpret_cast<unsigned*>(ex.zmax);
   }
-  return launch_mode<MODE_ROOT>(a, mm_unfused, (hipStream_t)stream);
+  return launch_forward<MODE_ROOT>(a, mm_unfused, (hipStream_t)stream,
+                                   groups == nullptr && a.cmask == nullptr ? ex.tail : nullptr);
 }
 
 }  // namespace
@@ -2758,7 +2980,9 @@ extern "C" {
 
 long long tempo_root_step_workspace(int B, int V, int H, int W, int CP, int chunk) {
   if (B <= 0 || V <= 0 || H <= 0 || W <= 0 || CP <= 0 || chunk <= 0) return TEMPO_E_DIM;
-  return (long long)(B < chunk ? B : chunk) * V * H * W * CP;
+  // one chunk's channel-last maps; two of them when the batch takes more than one chunk (the
+  // next chunk is repacked into the other half while the current one is unprojected)
+  return (long long)(B < chunk ? B : chunk) * V * H * W * CP * (B > chunk ? 2 : 1);
 }
 
 }  // extern "C"
@@ -2770,7 +2994,7 @@ int root_step_impl(const void* const* views, int C_total, int c_begin, const flo
                    const uint8_t* live, float* cubes, float* grids, void* mask,
                    int mask_bytes, int B, int V, int C, int CP, int H, int W, int X, int Y,
                    int Z, float hm_w, float hm_h, float img_w, float img_h, int mm_unfused,
-                   float* zmax, float* workspace, int chunk, void* stream) {
+                   float* zmax, float* workspace, int chunk, bool two_halves, void* stream) {
   if (views == nullptr || workspace == nullptr || cam == nullptr ||
       (cubes == nullptr && zmax == nullptr))
     return TEMPO_E_NULL;
@@ -2785,17 +3009,47 @@ int root_step_impl(const void* const* views, int C_total, int c_begin, const flo
     if (views[v] == nullptr) return TEMPO_E_NULL;
   const long long HW = (long long)H * W;
   const long long N = (long long)X * Y * Z;
+  const long long half = (long long)(B < chunk ? B : chunk) * V * HW * CP;  // floats per chunk
+  // With a workspace of two chunk-sized halves the repack of chunk c + 1 rides on the launch
+  // that unprojects chunk c (unproject_repack_kernel); it needs the wide repack's conditions
+  // (16-byte aligned planes).  Otherwise the chunks go through one buffer, one after the other.
+  // Both halves must stay in the 256 MB Infinity Cache together, or the rider evicts the maps
+  // being gathered: config 2, ms per 32-frame step, fused / one buffer: 8-frame chunks (2 x
+  // 79 MB) 0.277 / 0.297, 11 frames (2 x 108 MB) 0.280 / 0.299, 16 frames (2 x 158 MB)
+  // 0.301 / 0.270 -- so the default 16-frame chunks go through one buffer.
+  bool fuse = two_halves && B > chunk && half * 4 * 2 <= kFuseBytes && HW % 4 == 0 &&
+              ((long long)C_total * HW) % 4 == 0 && ((long long)c_begin * HW) % 4 == 0 &&
+              (half * 4) % 16 == 0;
+  for (int v = 0; v < V; v++) fuse = fuse && reinterpret_cast<uintptr_t>(views[v]) % 16 == 0;
+#ifdef TEMPO_NO_TAIL_FUSION
+  fuse = false;
+#endif
   const void* shifted[TEMPO_MAX_VIEWS];
   int err = TEMPO_OK;
-  for (int b0 = 0; b0 < B && err == TEMPO_OK; b0 += chunk) {
+  int ci = 0;
+  for (int b0 = 0; b0 < B && err == TEMPO_OK; b0 += chunk, ci++) {
     const int n = b0 + chunk <= B ? chunk : B - b0;
-    for (int v = 0; v < V; v++)
-      shifted[v] = static_cast<const float*>(views[v]) + (long long)b0 * C_total * HW;
-    err = tempo_repack_nhwc(shifted, V, n, C_total, c_begin, C, H, W, CP, workspace, stream);
-    if (err != TEMPO_OK) break;
+    float* buf = workspace + (fuse && (ci & 1) ? half : 0);
+    if (!fuse || b0 == 0) {
+      for (int v = 0; v < V; v++)
+        shifted[v] = static_cast<const float*>(views[v]) + (long long)b0 * C_total * HW;
+      err = tempo_repack_nhwc(shifted, V, n, C_total, c_begin, C, H, W, CP, buf, stream);
+      if (err != TEMPO_OK) break;
+    }
     Extra ex;
     ex.zmax = zmax ? zmax + (long long)b0 * C * X * Y : nullptr;
-    err = root_impl(workspace, cam + (long long)b0 * V * CAM_FLOATS,
+    RepackArgs tail;
+    if (fuse && b0 + chunk < B) {  // the next chunk, into the other half
+      const int b1 = b0 + chunk;
+      for (int v = 0; v < TEMPO_MAX_VIEWS; v++)
+        tail.views[v] = v < V ? static_cast<const float*>(views[v]) : nullptr;
+      tail.out = workspace + ((ci & 1) ? 0 : half);
+      tail.V = V; tail.B = b1 + chunk <= B ? chunk : B - b1;
+      tail.C_total = C_total; tail.c_begin = c_begin; tail.C = C;
+      tail.HW = (int)HW; tail.CP = CP; tail.b0 = b1;
+      ex.tail = &tail;
+    }
+    err = root_impl(buf, cam + (long long)b0 * V * CAM_FLOATS,
                     ax_x + (ax_batched ? (long long)b0 * X : 0),
                     ax_y + (ax_batched ? (long long)b0 * Y : 0),
                     ax_z + (ax_batched ? (long long)b0 * Z : 0), ax_batched,
@@ -2821,7 +3075,7 @@ int tempo_root_step(const void* const* views, int C_total, int c_begin, const fl
                     float* workspace, int chunk, void* stream) {
   return root_step_impl(views, C_total, c_begin, cam, ax_x, ax_y, ax_z, ax_batched, live, cubes,
                         grids, mask, mask_bytes, B, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w,
-                        img_h, mm_unfused, nullptr, workspace, chunk, stream);
+                        img_h, mm_unfused, nullptr, workspace, chunk, true, stream);
 }
 
 int tempo_root_step_zmax(const void* const* views, int C_total, int c_begin, const float* cam,
@@ -2834,7 +3088,7 @@ int tempo_root_step_zmax(const void* const* views, int C_total, int c_begin, con
   if (zmax == nullptr) return TEMPO_E_NULL;  // (cubes may be NULL: z-max alone)
   return root_step_impl(views, C_total, c_begin, cam, ax_x, ax_y, ax_z, ax_batched, live, cubes,
                         grids, mask, mask_bytes, B, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w,
-                        img_h, mm_unfused, zmax, workspace, chunk, stream);
+                        img_h, mm_unfused, zmax, workspace, chunk, true, stream);
 }
 
 }  // extern "C"
@@ -2895,9 +3149,11 @@ int tempo_root_step_static(const void* const* views, int C_total, int c_begin,
   if (e != TEMPO_OK) return e;
   // (nothing to clear: the repack overwrites every byte of a chunk's region, padding
   // channels included, before the unprojection of that chunk reads it)
-  return tempo_root_step(views, C_total, c_begin, cam, ax_x, ax_y, ax_z, ax_batched, live,
-                         cubes, grids, mask, mask_bytes, B, V, C, CP, H, W, X, Y, Z, hm_w, hm_h,
-                         img_w, img_h, mm_unfused, ws, chunk, stream);
+  // (one chunk-sized region of the array, chunks one after the other: two halves would halve
+  // the chunk that fits)
+  return root_step_impl(views, C_total, c_begin, cam, ax_x, ax_y, ax_z, ax_batched, live, cubes,
+                        grids, mask, mask_bytes, B, V, C, CP, H, W, X, Y, Z, hm_w, hm_h, img_w,
+                        img_h, mm_unfused, nullptr, ws, chunk, false, stream);
 }
 
 // ------------------------------------------- heatmaps read in place (channel-last views)
@@ -3042,7 +3298,7 @@ int window_impl(const Layout& lay, const float* cam, const int32_t* win_frame, c
   a.cubes = cubes;
   a.frame_stride = (long long)V * H * W * CP;
   a.view_bytes = (unsigned)((long long)H * W * CP * 4);
-  a.NB = NW; a.F = F; a.V = V; a.C = C; a.CP = CP; a.H = H; a.W = W;
+  a.NB = NW; a.F = F; a.V = V; a.C = C; a.Cs = C; a.CP = CP; a.H = H; a.W = W;
   a.dim[0] = VX; a.dim[1] = VY; a.dim[2] = VZ; a.N = (int)N;
   a.fdim[0] = FX; a.fdim[1] = FY; a.fdim[2] = FZ;
   a.geom = tempo_make_geom(hm_w, hm_h, img_w, img_h);
@@ -3067,9 +3323,9 @@ int window_impl(const Layout& lay, const float* cam, const int32_t* win_frame, c
     const hipError_t e = hipMemsetAsync(ex.ghm, 0, (size_t)F * a.frame_stride * sizeof(float),
                                         (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    return launch_backward<MODE_WINDOW>(a, mm_unfused, (hipStream_t)stream);
+    return launch_backward<MODE_WINDOW>(a, mm_unfused, (hipStream_t)stream, ex.tile);
   }
-  return launch_mode<MODE_WINDOW>(a, mm_unfused, (hipStream_t)stream);
+  return launch_forward<MODE_WINDOW>(a, mm_unfused, (hipStream_t)stream);
 }
 
 }  // namespace
@@ -3098,7 +3354,7 @@ int columns_impl(const Layout& lay, const float* cam, const float* ax_x, const f
   a.live = live;
   a.frame_stride = (long long)V * H * W * CP;
   a.view_bytes = (unsigned)((long long)H * W * CP * 4);
-  a.NB = B; a.F = B; a.V = V; a.C = C; a.CP = CP; a.H = H; a.W = W;
+  a.NB = B; a.F = B; a.V = V; a.C = C; a.Cs = C; a.CP = CP; a.H = H; a.W = W;
   a.dim[0] = 1; a.dim[1] = K; a.dim[2] = Z; a.N = K * Z;  // the virtual grid of the columns
   a.fdim[0] = X; a.fdim[1] = Y; a.fdim[2] = Z;            // the root grid the cells index
   a.geom = tempo_make_geom(hm_w, hm_h, img_w, img_h);

@@ -209,11 +209,31 @@ def unproject_root_backward(grad_cubes, cam, axes, clamp_mask, hm_shape, heatmap
     return ghm
 
 
+BACKWARD_TILE_PITCH = 2.2  # heatmap pixels per voxel from which the 144-texel tile pays
+
+
+def backward_tile_texels(cam_host, fine_axes_host, heatmap_size, image_size):
+    """Tile size for :func:`unproject_window_backward` from the lattice's pitch in heatmap
+    pixels: voxel pitch x focal length x affine scale x heatmap / image width, over the
+    cameras' distance to the middle of the lattice (host arithmetic on the packed camera
+    table, no device sync).  121 texels up to ``BACKWARD_TILE_PITCH`` pixels per voxel (config
+    3: 1.5), 144 beyond (H36M windows on 384 x 384 maps: 2.8; 5.00 -> 4.67 ms)."""
+    cam = cam_host.reshape(-1, 32)[:64].double()
+    ax = [a.double() for a in fine_axes_host]
+    mid = torch.stack([a[a.numel() // 2] for a in ax])
+    pitch_mm = max(float((a[-1] - a[0]).abs() / max(a.numel() - 1, 1)) for a in ax)
+    depth = (mid[None, :] @ cam[:, 0:9].reshape(-1, 3, 3))[:, 0, 2] + cam[:, 11]
+    px = pitch_mm * cam[:, 12].abs() * cam[:, 24].abs() * (heatmap_size[0] / image_size[0]) \
+        / depth.abs().clamp_min(1.0)
+    return 144 if float(px.median()) >= BACKWARD_TILE_PITCH else 121
+
+
 def unproject_window_backward(grad_cubes, cam, fine_axes, tl, start, end, clamp_mask,
                               hm_shape, heatmap_size, image_size, win_frame=None, live=None,
-                              mm_mode='auto'):
+                              mm_mode='auto', tile_texels=0):
     """Gradient of :func:`unproject_window`'s volume with respect to the repacked
-    heatmaps: ``grad_cubes [NW,C,VX,VY,VZ]`` -> ``[F,V,H,W,CP]``."""
+    heatmaps: ``grad_cubes [NW,C,VX,VY,VZ]`` -> ``[F,V,H,W,CP]``.  ``tile_texels``: 0
+    (library default), 121 or 144, see :func:`backward_tile_texels`."""
     lib = _lib.load()
     dev = grad_cubes.device
     _need(grad_cubes, torch.float32, 'grad_cubes')
@@ -240,7 +260,7 @@ def unproject_window_backward(grad_cubes, cam, fine_axes, tl, start, end, clamp_
             _ptr(ghm), NW, F_, V, C, CP, H, W, int(fa[0].numel()), int(fa[1].numel()),
             int(fa[2].numel()), VX, VY, VZ, float(heatmap_size[0]), float(heatmap_size[1]),
             float(image_size[0]), float(image_size[1]), numerics.abi_flag(mm_mode),
-            _stream_ptr(dev))
+            int(tile_texels), _stream_ptr(dev))
     _lib.check(rc, 'tempo_unproject_window_backward')
     return ghm
 

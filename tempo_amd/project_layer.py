@@ -206,7 +206,8 @@ class _Unproject(torch.autograd.Function):
                 ghm = ops.unproject_window_backward(
                     g, meta['cam'], meta['fine_axes'], meta['tl'], meta['start'], meta['end'],
                     cmask, hm_shape, meta['heatmap_size'], meta['image_size'],
-                    live=meta['live'], mm_mode=meta['mm_mode'])
+                    live=meta['live'], mm_mode=meta['mm_mode'],
+                    tile_texels=meta.get('tile_texels', 0))
             else:
                 ghm = ops.unproject_root_backward(
                     g, meta['cam'], meta['axes'], cmask, hm_shape, meta['heatmap_size'],
@@ -649,10 +650,9 @@ class ProjectLayerWithMask(nn.Module):
         if self._fine_axes is not None:
             return
         center, size, sub = self._space
-        self._fine_axes = [
-            (_base_axis(size[i], self._fine_bins[i]) + center[i]).to(device)
-            for i in range(3)
-        ]
+        self._fine_axes_host = [_base_axis(size[i], self._fine_bins[i]) + center[i]
+                                for i in range(3)]
+        self._fine_axes = [a.to(device) for a in self._fine_axes_host]
         vx = self._sub_cube
         ax = [_base_axis(sub[i], vx[i]) + center[i] for i in range(3)]
         gx, gy, gz = torch.meshgrid(*ax, indexing='ij')
@@ -683,8 +683,8 @@ class ProjectLayerWithMask(nn.Module):
             if grid_center.shape[1] != 3:
                 live = (grid_center[:, 3] >= 0).to(torch.uint8).contiguous()
         self._ensure_grids(device)
-        cam = to_device(pack_cameras(centers, scales, cameras, self.image_size,
-                                     self.mm_mode), device)
+        self._cam_host = pack_cameras(centers, scales, cameras, self.image_size, self.mm_mode)
+        cam = to_device(self._cam_host, device)
         geo = tuple(t.to(torch.int32).contiguous() for t in (centers_tl, start, end))
         return device, B, C, offset, live, cam, geo
 
@@ -692,10 +692,15 @@ class ProjectLayerWithMask(nn.Module):
         device, B, C, offset, live, cam, (tl, st, en) = self._window_inputs(
             feature_maps, grid_center, centers, scales, cameras)
         if _wants_grad(feature_maps):  # training: differentiable path
+            # the backward's LDS tile: from the lattice's pitch in heatmap pixels, unless set
+            tile = int(getattr(self, 'backward_tile', 0) or 0)
+            if tile == 0 and not self._cam_host.is_cuda:
+                tile = ops.backward_tile_texels(self._cam_host, self._fine_axes_host,
+                                                self.heatmap_size, self.image_size)
             meta = dict(kind='window', cam=cam, fine_axes=self._fine_axes, tl=tl, start=st,
                         end=en, sub_cube=list(self._sub_cube), live=live,
                         heatmap_size=self.heatmap_size, image_size=self.image_size,
-                        mm_mode=self.mm_mode)
+                        mm_mode=self.mm_mode, tile_texels=tile)
             cubes = _Unproject.apply(meta, *[fm.float() for fm in feature_maps])
             return cubes, offset
         cubes = torch.empty(B, C, *self._sub_cube, dtype=torch.float32, device=device)

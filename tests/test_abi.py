@@ -98,8 +98,9 @@ def test_new_entry_points_reject_bad_arguments():
     wbwd = lambda **kw: lib.tempo_unproject_window_backward(
         one, one, None, one, one, one, one, one, one, None, one, kw.get('ghm', one),
         kw.get('NW', 4), 4, 5, 15, 16, 128, 240, 253, 253, 64, 64, 64, 64, 240.0, 128.0, 960.0,
-        512.0, 0, None)
+        512.0, 0, kw.get('tile', 0), None)
     assert wbwd(ghm=None) == -1 and wbwd(NW=8) == -5
+    assert wbwd(tile=100) == -5 and wbwd(tile=-1) == -5  # 0 (default), 121 or 144
     assert lib.tempo_clamp_mask_words(128000, 16) == 2000 * 16
     assert lib.tempo_clamp_mask_words(65, 20) == 2 * 24
     assert lib.tempo_clamp_mask_words(0, 16) == -2 and lib.tempo_clamp_mask_words(64, 18) == -3

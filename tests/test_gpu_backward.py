@@ -80,8 +80,9 @@ def test_window_backward_vs_autograd(name, gpu_device):
     _grads_close([f.grad for f in fms], ref_grads, name)
 
 
+@pytest.mark.parametrize('tile', [0, 121, 144])
 @pytest.mark.parametrize('sub_mm,cube', [(400, 16), (560, 14), (800, 16)])
-def test_window_backward_fine_lattices(sub_mm, cube, gpu_device):
+def test_window_backward_fine_lattices(sub_mm, cube, tile, gpu_device):
     """The window backward sums each 4x4x4 brick's footprints in an LDS tile before
     touching memory when the brick's footprint box fits the tile, retries the brick
     as two halves when it does not, and falls back to per-sample atomics last.
@@ -101,6 +102,7 @@ def test_window_backward_fine_lattices(sub_mm, cube, gpu_device):
     weight = torch.randn(ref_cubes.shape, generator=g)
     (ref_cubes * weight).sum().backward()
     layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    layer.backward_tile = tile  # 0: chosen from the lattice's pitch; both sizes must agree
     fms = _leafs(base, gpu_device)
     cubes, _ = layer(fms, args[1].to(gpu_device), *args[2:])
     assert float((cubes.detach().cpu() - ref_cubes.detach()).abs().max()) <= 1e-5
