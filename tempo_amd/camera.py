@@ -15,6 +15,8 @@ Every value is produced with the same fp32/fp64 host operations the reference
 would run (torch CPU ops for the tensors, a float64 6x6 solve for the affine),
 so the table is bit-identical to what the reference's camera objects hold.
 """
+import itertools
+
 import numpy as np
 import torch
 
@@ -203,10 +205,9 @@ def _record_for(param, mm_mode):
 # (tempo_pose.py:145-156, :266), the detector once per timestep -- and building the content
 # keys of 160 dicts costs ~1 ms of host time.  Key = identities of the per-frame lists;
 # an entry keeps those lists alive (so an id cannot be reused) and a fingerprint of every
-# dict (identity of the dict and of its R / T / K values, two sampled numbers), so that a
-# replaced or rebuilt dict is seen.  Calibration VALUES mutated in place inside an array that
-# was passed before are not re-read: treat passed calibrations as constants, or call
-# ``clear_cache()``.
+# dict: its identity and the bytes of its calibration fields, centre and scale, so that a
+# replaced or rebuilt dict and a value edited in place are both seen.
+_chain = itertools.chain.from_iterable
 _TABLES = {}
 _TABLES_MAX = 64
 
@@ -236,20 +237,31 @@ def to_device(table, device):
     return dev
 
 
-def _num(x):
-    while not isinstance(x, (int, float)):
-        x = x[0]
-    return float(x)
+def _blob(x):
+    """The bytes of one calibration field (ndarray: its own buffer; lists and scalars go
+    through a float64 array)."""
+    if isinstance(x, np.ndarray):
+        return x.tobytes()
+    if isinstance(x, (str, bytes)):
+        return x
+    return np.asarray(x, dtype=np.float64).tobytes()
 
 
 def _fingerprint(centers, scales, cameras):
-    fp = []
-    for cb, sb, mb in zip(centers, scales, cameras):
-        for c, sc, m in zip(cb, sb, mb):
-            r, t = m.get('R'), m.get('T')
-            fp.append((id(m), id(r), id(t), id(m.get('K', m.get('f'))), len(m),
-                       _num(r), _num(t), float(c[0]), float(c[1]), float(sc[0])))
-    return fp
+    """What a cached table was built from: the identity of every dict, of every key and of
+    every value object, the bytes of every centre and scale, and -- once per distinct value
+    object: the frames of a recording share their calibration arrays -- the BYTES of every
+    value.  A replaced dict, a replaced field and a number edited in place inside a list or
+    array that was passed before all change the fingerprint (the earlier form
+    sampled two numbers per dict and never matched for float32 scalars).  Built with C-level
+    iteration only: ~0.1 ms for 160 dicts."""
+    dicts = list(_chain(cameras))
+    vals = list(_chain(m.values() for m in dicts))
+    vids = list(map(id, vals))
+    distinct = dict(zip(vids, vals))
+    return (list(map(id, dicts)), list(_chain(dicts)), vids,
+            [_blob(v) for v in distinct.values()],
+            [_blob(c) for c in _chain(centers)], [_blob(sc) for sc in _chain(scales)])
 
 
 def pack_cameras(centers, scales, cameras, image_size, mm_mode='auto'):

@@ -264,15 +264,12 @@ __device__ __forceinline__ void zmax_clear_columns(const UnprojArgs& a, int b, i
                                                    int lane) {
   const int Z = a.dim[2];
   const int cols = a.wave_vox / Z;
+  const int q0 = n0 / Z, ncol = a.dim[0] * a.dim[1];
   for (int s0 = 0; s0 < cols * a.C; s0 += kWaveVox) {
     const int slot = s0 + lane;
     const int c = slot / a.C, ch = slot - c * a.C;
-    const int nc = n0 + c * Z;
-    if (c < cols && nc < a.N) {
-      int j0, j1, j2;
-      voxel_index(a, nc, &j0, &j1, &j2);
-      a.pl01[(((long long)b * a.Cs + ch) * a.dim[0] + j0) * a.dim[1] + j1] = 0u;
-    }
+    if (c < cols && q0 + c < ncol)
+      a.pl01[((long long)b * a.Cs + ch) * ncol + q0 + c] = 0u;
   }
 }
 
@@ -283,6 +280,7 @@ __device__ __forceinline__ void zmax_clear_columns(const UnprojArgs& a, int b, i
 // patterns order like unsigned integers and NaN (larger than 1.0f) wins, as in
 // torch.max.  Along the fastest axis the wave reduces in registers when it
 // holds exactly one column; everything else is a no-return atomic max.
+template <int CH>  // channel slots of the tile (4 L)
 __device__ __forceinline__ void planes_epilogue(const UnprojArgs& a, int b, int n0, int lane,
                                                 const float* s_out, int tstr) {
   const int n = n0 + lane;
@@ -294,26 +292,26 @@ __device__ __forceinline__ void planes_epilogue(const UnprojArgs& a, int b, int 
   // first lane stores it (no atomic, no zero-initialised plane)
   const bool whole = !column && a.wave_vox % a.dim[2] == 0;
   if (whole && a.pl01 != nullptr && a.pl02 == nullptr && a.pl12 == nullptr) {
-    // lane = (column of the wave, channel): the column's Z values are read straight out of
-    // the tile (rows of different channels and columns fall into different banks) and the
-    // maximum is stored -- no cross-lane traffic at all
+    // lane = (column of the wave, channel slot): the column's Z values are read straight out
+    // of the tile (rows of different channels and columns fall into different banks) and the
+    // maximum is stored -- no cross-lane traffic at all.  n0 is a multiple of Z here, so the
+    // column's place in the [X][Y] plane is n0 / Z + column: no index arithmetic per lane.
     const int Z = a.dim[2];
     const int cols = a.wave_vox / Z;
-    for (int s0 = 0; s0 < cols * a.C; s0 += kWaveVox) {
-      const int slot = s0 + lane;
-      const int c = slot / a.C, ch = slot - c * a.C;
-      const int nc = n0 + c * Z;  // first voxel of the column
-      if (c < cols && nc < a.N) {
+    const int q0 = __builtin_amdgcn_readfirstlane(n0 / Z);
+    const int ncol = a.dim[0] * a.dim[1];
+    for (int c0 = 0; c0 < cols; c0 += kWaveVox / CH) {
+      const int c = c0 + lane / CH, ch = lane % CH;
+      if (c < cols && ch < a.C && q0 + c < ncol) {
         const float* col = s_out + ch * tstr + c * Z;
         unsigned m = 0u;
+#pragma unroll 4
         for (int k = 0; k < Z; k++) {
           unsigned v = __float_as_uint(col[k]);
           v = v == 0x80000000u ? 0u : v;  // -0.0 orders as +0.0
           m = v > m ? v : m;
         }
-        int j0, j1, j2;
-        voxel_index(a, nc, &j0, &j1, &j2);
-        a.pl01[(((long long)b * a.Cs + ch) * a.dim[0] + j0) * a.dim[1] + j1] = m;
+        a.pl01[((long long)b * a.Cs + ch) * ncol + q0 + c] = m;
       }
     }
     return;
@@ -372,6 +370,11 @@ __device__ __forceinline__ void planes_epilogue(const UnprojArgs& a, int b, int 
 // results in the denormal range, where that form can miss an exact tie, are redone with
 // the plain division.  Returns true (wave-uniform) when a NaN or such a result is present
 // anywhere in the wave: the caller then clamps NaN-aware.
+// (One case is not tested for: a product that rounds to zero while the true quotient rounds
+// to the smallest denormal, i.e. a quotient within 2^-50, relatively, of 2^-150.  With a
+// denormal numerator k * 2^-149 that needs a denominator within 2^-50 of the even integer 2 k,
+// and the denominators here are count + 1e-6 rounded to fp32, at least 9.5e-7 above an
+// integer: it cannot occur.  tools/verify_constdiv.c says the same for its divisors.)
 struct DenRec {
   double r;   // 1 / den
   float den;  // (float)count + 1e-6f
@@ -860,7 +863,7 @@ __device__ __forceinline__ void unproject_block(const UnprojArgs& a, int bid,
     store_tile(a.cubes + (long long)b * a.Cs * a.N, a.C, a.N, n, s_out + lane, TSTR);
   }
   if (a.pl01 != nullptr || a.pl02 != nullptr || a.pl12 != nullptr)
-    planes_epilogue(a, b, n0, lane, s_out, TSTR);
+    planes_epilogue<4 * L>(a, b, n0, lane, s_out, TSTR);
 #ifdef TEMPO_TIMELINE
   if (a.grids != nullptr) {
     constexpr int tl_off = wave_lds_bytes(L) - kTimelineBytes;
@@ -2313,8 +2316,14 @@ int launch_one(const UnprojArgs& a, hipStream_t stream, const RepackArgs* tail =
   // (wider texels: two sub-steps keep the fetch registers at 32 and the occupancy up;
   // 20 channels 0.38 -> 0.31 ms, 32 channels 0.53 -> 0.49 ms at config 2's shape)
   // (window, 28-32 channels: two sub-steps, 8.07 -> 7.58 ms at config 3's shape)
-  constexpr int SB = MODE == MODE_ROOT ? (L == 4 ? TEMPO_SB_ROOT : 2)
-                                       : (L >= 7 ? 2 : TEMPO_SB_WINDOW);
+#ifndef TEMPO_SB_ROOT_WIDE
+#define TEMPO_SB_ROOT_WIDE 2
+#endif
+#ifndef TEMPO_SB_WINDOW_WIDE
+#define TEMPO_SB_WINDOW_WIDE 2
+#endif
+  constexpr int SB = MODE == MODE_ROOT ? (L == 4 ? TEMPO_SB_ROOT : TEMPO_SB_ROOT_WIDE)
+                                       : (L >= 7 ? TEMPO_SB_WINDOW_WIDE : TEMPO_SB_WINDOW);
   UnprojArgs k = a;
   fill_order_magic(k.order, k.magic, a.V, a.dim);
   const int waves = kThreads / 64;
@@ -2348,10 +2357,14 @@ int launch_one(const UnprojArgs& a, hipStream_t stream, const RepackArgs* tail =
   // root z-max (the only plane asked for): waves of whole z-columns, so that every column's
   // maximum is complete inside one wave and is stored instead of max-accumulated with
   // atomics (config 2: 60 of 64 lanes busy; the fused z-max then costs +0.03 instead of
-  // +0.07 ms per step)
+  // +0.07 ms per step).  Full waves in workgroups of 5 (320 voxels = 16 whole columns, the
+  // maxima read across the waves' tiles after one workgroup barrier) were measured at
+  // 0.261 against 0.200 ms: the barrier takes away the waves' autonomy, which costs far more
+  // than the 4 idle lanes.
   if (MODE == MODE_ROOT && a.pl01 != nullptr && a.pl02 == nullptr && a.pl12 == nullptr &&
-      a.cmask == nullptr)
+      a.cmask == nullptr) {
     k.wave_vox = zmax_wave_vox(a.dim[2]);
+  }
   k.tile_vox = kTileWaves * k.wave_vox;
   k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
   const long long total = (long long)a.NB * k.tiles;

@@ -16,6 +16,12 @@ def _stream_ptr(device):
 
 
 _STAGING = {}
+STAGING_MAX_BYTES = 512 << 20  # larger requests are plain allocations, not kept
+
+
+def release_staging():
+    """Drop the persistent staging buffers (see :func:`_staging`); they come back on demand."""
+    _STAGING.clear()
 
 
 def _staging(dev, numel):
@@ -23,7 +29,13 @@ def _staging(dev, numel):
     of ``dev`` (the channel-last maps of one chunk: written and read inside one call, dead
     afterwards).  Kept across calls, grow-only, instead of asking the caching allocator for
     ~100 MB per call.  One buffer per (device, stream): calls on different streams do not
-    share it."""
+    share it.  Not kept: requests above ``STAGING_MAX_BYTES`` (a whole batch's maps for the
+    one-launch planes step), and anything asked for while the stream is being captured into
+    a graph (the allocation would belong to the capture's private pool);
+    :func:`release_staging` frees the rest."""
+    numel = int(numel)
+    if numel * 4 > STAGING_MAX_BYTES or torch.cuda.is_current_stream_capturing():
+        return torch.empty(numel, dtype=torch.float32, device=dev)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(),
            torch.cuda.current_stream(dev).cuda_stream)
     buf = _STAGING.get(key)
@@ -32,7 +44,7 @@ def _staging(dev, numel):
         _STAGING.pop(key, None)
         if len(_STAGING) > 16:
             _STAGING.clear()
-        buf = torch.empty(int(numel), dtype=torch.float32, device=dev)
+        buf = torch.empty(numel, dtype=torch.float32, device=dev)
         _STAGING[key] = buf
     return buf
 

@@ -292,3 +292,35 @@ def test_window_planes_on_maps_in_place(want_cubes, gpu_device):
     for name in ('channels_last', 'packed'):
         for a, b in zip(outs[name][:3], outs['nchw'][:3]):
             assert torch.equal(_canon(a), _canon(b)), name
+
+
+def test_channel_slices_at_the_end_of_an_allocation(gpu_device):
+    """a channel slice of a channels_last tensor is handed over as a shifted
+    pointer; the fetch lanes cover CP channels, so the last texels of the last frame used to
+    be read up to 4 * (CP - C) bytes past the tensor.  The buffer range of a map now ends with
+    the slice's last channel (per-dword range check: tools/range_check.hip).  40 channels go
+    through the module as slices of 32 + 8 (CP = 16 for the second: 32 bytes that do not
+    exist); the tensors sit at the very end of their allocations."""
+    import tempo_amd
+    from tempo_amd import synthetic as S
+    dev = gpu_device
+    cfg = dict(S.PANOPTIC, heatmap_size=[24, 14], num_joints=40)
+    V, B, C, H, W = 5, 2, 40, 14, 24
+    cams = S.ring_cameras(V, seed=81, target=cfg['space_center'])
+    centers, scales, cameras = S.frame_meta(cams, B, cfg['raw_size'], cfg['image_size'])
+    g = torch.Generator().manual_seed(82)
+    nchw = [torch.rand(B, C, H, W, generator=g).to(dev) for _ in range(V)]
+    nhwc = []
+    for f in nchw:
+        raw = torch.empty(B * H * W * C, dtype=torch.float32, device=dev)  # exactly the bytes
+        t = torch.as_strided(raw, (B, C, H, W), (H * W * C, 1, W * C, C))
+        t.copy_(f)
+        assert t.data_ptr() + t.numel() * 4 == raw.data_ptr() + raw.numel() * 4
+        nhwc.append(t)
+    layer = tempo_amd.ProjectLayer(cfg['image_size'], cfg['heatmap_size'], 'mean')
+    args = (cfg['space_size'], [cfg['space_center']], [10, 9, 7], centers, scales, cameras)
+    with torch.no_grad():
+        ref, _ = layer(nchw, *args)
+        got, _ = layer(nhwc, *args)
+    torch.cuda.synchronize()
+    assert torch.equal(_canon(got), _canon(ref)) and float(ref[:, 32:].max()) > 0.0

@@ -3,7 +3,11 @@
 // steps on an fp32 estimate that is a few ulp off (what the kernel's v_rcp_f32 gives).
 // Mismatches are counted apart for results in the fp32 denormal range, where the form
 // may miss exact ties (the kernels redo those: normalise_tile) -- everywhere else the
-// count must be 0.
+// count must be 0.  normalise_tile recognises such a result by its DENORMAL class; a product
+// that rounds to zero while the true quotient rounds to 2^-149 (a quotient within 2^-50 of
+// 2^-150) would escape that test.  It needs a divisor within 2^-50, relatively, of an even
+// integer multiple of the numerator's 2^-149 count; the kernels' divisors there are
+// count + 1e-6, so it cannot occur, and this program counts such results with the ties.
 //   gcc -O2 -fopenmp -ffp-contract=off tools/verify_constdiv.c -o /tmp/vcd -lm && /tmp/vcd 960 512 239 127 ...
 #include <math.h>
 #include <stdint.h>
