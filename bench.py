@@ -69,7 +69,7 @@ def parse(argv=None):
                          'from the heatmaps, so that the volume is never written')
     ap.add_argument('--columns', type=int, default=10,
                     help='--zmax only: z-columns per frame (the detector\'s top-K cells)')
-    ap.add_argument('--min-seconds', type=float, default=1.5,
+    ap.add_argument('--min-seconds', type=float, default=3.0,
                     help='the number of timed blocks is raised until the timed region lasts at '
                          'least this long (steps per block stay as given)')
     ap.add_argument('--backward', action='store_true',

@@ -436,10 +436,6 @@ class ProjectLayer(nn.Module):
 
     def _consumer_inputs(self, feature_maps, grid_size, grid_center, cube_size, centers, scales,
                          cameras, what):
-        if _requires_grad(feature_maps):
-            raise NotImplementedError(
-                f'{what} is forward-only (no gradient reaches the feature maps through it); '
-                'use forward() + the torch ops for training')
         device = _check_inputs(feature_maps)
         B, C = _batch_channels(feature_maps)
         live = self._live(grid_center, B, device)
@@ -454,7 +450,13 @@ class ProjectLayer(nn.Module):
         thing the root detector computes from the volume (``center_net.py:230``) -- without
         the volume: ``[B,C,X,Y]``, bit-identical, 246 MB of stores fewer at the Panoptic
         batch.  Arguments as :meth:`forward`.  The volume's only other consumer, the K
-        z-columns of ``tempo_detector.py:204-206``, comes from :meth:`zcolumns`."""
+        z-columns of ``tempo_detector.py:204-206``, comes from :meth:`zcolumns`.  When a feature
+        map requires a gradient the call goes through :meth:`forward` and ``torch.max``
+        (differentiable, unfused)."""
+        if _wants_grad(feature_maps):  # training: the volume and autograd's own torch.max
+            cubes, _ = self.get_voxel(feature_maps, grid_size, grid_center, cube_size, centers,
+                                      scales, cameras)
+            return torch.max(cubes, dim=4)[0]
         device, B, C, live, axes, cube_size, cam = self._consumer_inputs(
             feature_maps, grid_size, grid_center, cube_size, centers, scales, cameras,
             'forward_zmax')
@@ -485,6 +487,13 @@ class ProjectLayer(nn.Module):
         index[..., None, None].repeat(1, 1, C, Z))`` of ``tempo_detector.py:204-206``,
         computed from the heatmaps (only those K * Z voxels are unprojected): bit-identical
         to gathering from :meth:`forward`'s volume, which need not exist."""
+        if _wants_grad(feature_maps):  # training: the detector's own expression on the volume
+            cubes, _ = self.get_voxel(feature_maps, grid_size, grid_center, cube_size, centers,
+                                      scales, cameras)
+            B_, C_, Z_ = cubes.shape[0], cubes.shape[1], cubes.shape[4]
+            idx = index.to(device=cubes.device, dtype=torch.int64).view(B_, -1, 1, 1)
+            return torch.gather(torch.flatten(cubes, 2, 3).permute(0, 2, 1, 3), dim=1,
+                                index=idx.repeat(1, 1, C_, Z_))
         device, B, C, live, axes, cube_size, cam = self._consumer_inputs(
             feature_maps, grid_size, grid_center, cube_size, centers, scales, cameras,
             'zcolumns')
@@ -521,8 +530,10 @@ class ProjectLayer(nn.Module):
         (bit-identical; forward-only, grids are not materialised)."""
         T = len(feature_maps_t)
         device = _check_inputs(feature_maps_t[0])
-        if any(_wants_grad(f) for f in feature_maps_t):
-            raise NotImplementedError('forward_sequence is forward-only; loop over forward()')
+        if any(_wants_grad(f) for f in feature_maps_t):  # training: the caller's own loop
+            return torch.cat([self.forward(feature_maps_t[t], grid_size, grid_center_t[t],
+                                           cube_size, centers_t[t], scales_t[t],
+                                           cameras_t[t])[0] for t in range(T)], dim=0)
         B, C = feature_maps_t[0][0].shape[:2]
         ax, lives = [], []
         for t in range(T):
@@ -738,8 +749,12 @@ class ProjectLayerWithMask(nn.Module):
         cubes | None)``; with ``want_cubes=False`` the ``[B,C,X,Y,Z]`` volume is never
         written to memory."""
         if _wants_grad(feature_maps):
-            raise NotImplementedError(
-                'get_planes is forward-only; use forward() + torch.max for training')
+            # training: the volume through the differentiable path and autograd's own
+            # torch.max (tempo_pose.py:172-176 as written); a planes-gradient backward was
+            # priced at 12 ms against this path's 19 and not built (DESIGN.md section 4)
+            cubes, offset = self.get_voxel(feature_maps, grid_center, centers, scales, cameras)
+            return (torch.max(cubes, dim=4)[0], torch.max(cubes, dim=3)[0],
+                    torch.max(cubes, dim=2)[0], offset, cubes if want_cubes else None)
         device, B, C, offset, live, cam, (tl, st, en) = self._window_inputs(
             feature_maps, grid_center, centers, scales, cameras)
         vx, vy, vz = self._sub_cube
@@ -784,9 +799,19 @@ class ProjectLayerWithMask(nn.Module):
         ``[B,P,T,C,X,Y,Z]`` when ``want_cubes`` (else None: never written)."""
         T = len(feature_maps_t)
         device = _check_inputs(feature_maps_t[0])
-        if any(_wants_grad(f) for f in feature_maps_t):
-            raise NotImplementedError('forward_sequence_planes is forward-only')
         self.set_space_size(space_center, space_size, sub_space_size, sub_cube_size, device)
+        if any(_wants_grad(f) for f in feature_maps_t):
+            # training: the caller's two loops as written (tempo_pose.py:145-156, :266), each
+            # call through the differentiable path
+            P_ = candidates.shape[1]
+            rows = [[self.get_planes(feature_maps_t[t], candidates[:, n].to(device),
+                                     centers_t[t], scales_t[t], cameras_t[t],
+                                     want_cubes=want_cubes) for t in range(T)]
+                    for n in range(P_)]
+            pick = lambda k: torch.stack([torch.stack([rows[n][t][k] for t in range(T)], 1)
+                                          for n in range(P_)], 1)
+            offset = torch.stack([rows[n][0][3] for n in range(P_)], 1)
+            return pick(0), pick(1), pick(2), offset, (pick(4) if want_cubes else None)
         B, C = feature_maps_t[0][0].shape[:2]
         V = len(feature_maps_t[0])
         H, W = feature_maps_t[0][0].shape[2:]

@@ -145,28 +145,60 @@ def test_detector_path_without_the_volume_vs_oracle(gpu_device):
                          index=index.to(gpu_device).view(B, -1, 1, 1).repeat(1, 1, C, Z))))
 
 
-def test_forward_only_shortcuts_refuse_to_drop_gradients(gpu_device):
-    """the fused consumers and the z-column gather have no backward; with autograd
-    recording and an input that asks for a gradient they raise instead of cutting the graph."""
+def test_fused_consumers_under_autograd(gpu_device):
+    """no shortcut may silently cut the autograd graph.  The module-level consumers
+    (forward_zmax, zcolumns, get_planes) fall back to forward() + the torch expression when a
+    feature map requires a gradient -- gradients equal autograd through the oracle's op chain;
+    the raw forward-only ops (gather_zcolumns on a volume that requires grad, PackedHeatmaps
+    that require grad) raise."""
     import tempo_amd
     from tempo_amd import ops
-    case = cases.to_device(cases.build_root('root_panoptic_noise'), gpu_device)
+    case = cases.build_root('root_panoptic_noise')
+    ref_fms = [f.clone().requires_grad_(True) for f in case['args'][0]]
+    ref_cubes, _ = O.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')(
+        ref_fms, *case['args'][1:])
+    B, C, X, Y, Z = ref_cubes.shape
+    g = torch.Generator().manual_seed(4)
+    wz = torch.randn(B, C, X, Y, generator=g)
+    index = torch.randint(0, X * Y, (B, 4), generator=g)
+    wc = torch.randn(B, 4, C, Z, generator=g)
+    ref_cols = torch.gather(torch.flatten(ref_cubes, 2, 3).permute(0, 2, 1, 3), dim=1,
+                            index=index.view(B, -1, 1, 1).repeat(1, 1, C, Z))
+    ((ref_cubes.max(dim=4)[0] * wz).sum() + (ref_cols * wc).sum()).backward()
+
+    dcase = cases.to_device(case, gpu_device)
     layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
-    args = list(case['args'])
-    args[0] = [f.clone().requires_grad_(True) for f in args[0]]
+    fms = [f.clone().requires_grad_(True) for f in dcase['args'][0]]
+    zmax = layer.forward_zmax(fms, *dcase['args'][1:])
+    cols = layer.zcolumns(fms, *dcase['args'][1:], index.to(gpu_device))
+    assert zmax.requires_grad and cols.requires_grad
+    ((zmax * wz.to(gpu_device)).sum() + (cols * wc.to(gpu_device)).sum()).backward()
+    for a, b in zip(fms, ref_fms):
+        assert float((a.grad.cpu() - b.grad).abs().max()) <= 2e-5 * max(1.0, float(b.grad.abs().max()))
+    cubes, _ = layer(fms, *dcase['args'][1:])
     with pytest.raises(NotImplementedError):
-        layer.forward_zmax(*args)
-    index = torch.zeros(1, 2, dtype=torch.int64, device=gpu_device)
-    with pytest.raises(NotImplementedError):
-        layer.zcolumns(*args, index)
-    cubes, _ = layer(*args)  # the differentiable path
-    assert cubes.requires_grad
-    with pytest.raises(NotImplementedError):
-        ops.gather_zcolumns(cubes, index)
+        ops.gather_zcolumns(cubes, index.to(gpu_device))
     with torch.no_grad():
-        ops.gather_zcolumns(cubes, index)
-    packed = tempo_amd.PackedHeatmaps(ops.repack_nhwc(case['args'][0]).requires_grad_(True), 15)
+        ops.gather_zcolumns(cubes, index.to(gpu_device))
+    packed = tempo_amd.PackedHeatmaps(
+        ops.repack_nhwc(dcase['args'][0]).requires_grad_(True), 15)
     with pytest.raises(NotImplementedError):
-        layer(packed, *case['args'][1:])
+        layer(packed, *dcase['args'][1:])
     with torch.no_grad():
-        layer(packed, *case['args'][1:])
+        layer(packed, *dcase['args'][1:])
+
+    # window planes: get_planes under autograd == oracle volume + torch.max
+    wcase = cases.build_window('win_h36m_noise')
+    rf = [f.clone().requires_grad_(True) for f in wcase['args'][0]]
+    rc, _ = O.ProjectLayerWithMask(wcase['image_size'], wcase['heatmap_size'], 'mean')(
+        rf, *wcase['args'][1:])
+    ws = [torch.randn(rc.max(dim=d)[0].shape, generator=g) for d in (4, 3, 2)]
+    sum((rc.max(dim=d)[0] * w).sum() for d, w in zip((4, 3, 2), ws)).backward()
+    wl = tempo_amd.ProjectLayerWithMask(wcase['image_size'], wcase['heatmap_size'], 'mean')
+    dw = cases.to_device(wcase, gpu_device)
+    gf = [f.clone().requires_grad_(True) for f in dw['args'][0]]
+    wl.set_space_size(*dw['args'][2:6], gpu_device)
+    planes = wl.get_planes(gf, dw['args'][1], *dw['args'][6:])
+    sum((p * w.to(gpu_device)).sum() for p, w in zip(planes[:3], ws)).backward()
+    for a, b in zip(gf, rf):
+        assert float((a.grad.cpu() - b.grad).abs().max()) <= 2e-5 * max(1.0, float(b.grad.abs().max()))
