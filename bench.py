@@ -865,12 +865,17 @@ def main():
     # of the default workload lasts a few ms, too short for the clocks to settle or for an
     # outside observer (the driver samples GPU activity) to see the GPU working: the number
     # of blocks is raised until the timed region lasts --min-seconds (every rank computes the
-    # same count from the max-over-ranks time of the first block).
+    # same count from the max-over-ranks times of two probe blocks; the first block of a
+    # process can run several times slower than the steady state -- clocks ramping up -- so the
+    # faster of the two sizes the region).
     block_s = [timed_block()]
     blocks = max(1, args.blocks)
-    if not args.dry_run and block_s[0] > 0:
-        blocks = max(blocks, min(5000, int(args.min_seconds / block_s[0]) + 1))
-    for _ in range(blocks - 1):
+    if not args.dry_run and args.min_seconds > 0:
+        block_s.append(timed_block())
+        est = min(block_s)
+        if est > 0:
+            blocks = max(blocks, min(20000, int(args.min_seconds / est) + 1))
+    for _ in range(blocks - len(block_s)):
         block_s.append(timed_block())
     elapsed = sorted(block_s)[len(block_s) // 2]
 
