@@ -16,6 +16,7 @@ would run (torch CPU ops for the tensors, a float64 6x6 solve for the affine),
 so the table is bit-identical to what the reference's camera objects hold.
 """
 import itertools
+import marshal
 
 import numpy as np
 import torch
@@ -238,13 +239,29 @@ def to_device(table, device):
 
 
 def _blob(x):
-    """The bytes of one calibration field (ndarray: its own buffer; lists and scalars go
-    through a float64 array)."""
+    """The bytes of one calibration field (ndarray: its own buffer; nested lists of python
+    numbers: their marshal form, exact and one C call; anything else goes through a float64
+    array)."""
     if isinstance(x, np.ndarray):
         return x.tobytes()
     if isinstance(x, (str, bytes)):
         return x
+    if isinstance(x, (list, tuple)):
+        try:
+            return marshal.dumps(x)
+        except ValueError:  # numpy scalars, arrays or tensors inside
+            pass
     return np.asarray(x, dtype=np.float64).tobytes()
+
+
+def _blobs(items):
+    """:func:`_blob` of every item; all-ndarray input (the usual centres and scales) without a
+    python-level call per item."""
+    items = list(items)
+    try:
+        return list(map(np.ndarray.tobytes, items))
+    except TypeError:
+        return [_blob(x) for x in items]
 
 
 def _fingerprint(centers, scales, cameras):
@@ -256,12 +273,11 @@ def _fingerprint(centers, scales, cameras):
     sampled two numbers per dict and never matched for float32 scalars).  Built with C-level
     iteration only: ~0.1 ms for 160 dicts."""
     dicts = list(_chain(cameras))
-    vals = list(_chain(m.values() for m in dicts))
+    vals = list(_chain(map(dict.values, dicts)))  # (TypeError for a non-dict: full path)
     vids = list(map(id, vals))
     distinct = dict(zip(vids, vals))
-    return (list(map(id, dicts)), list(_chain(dicts)), vids,
-            [_blob(v) for v in distinct.values()],
-            [_blob(c) for c in _chain(centers)], [_blob(sc) for sc in _chain(scales)])
+    return (list(map(id, dicts)), list(_chain(dicts)), vids, _blobs(distinct.values()),
+            _blobs(_chain(centers)), _blobs(_chain(scales)))
 
 
 def pack_cameras(centers, scales, cameras, image_size, mm_mode='auto'):

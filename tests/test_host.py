@@ -160,3 +160,47 @@ def test_packed_table_cache_sees_replaced_calibrations():
     camera.clear_cache()
     f = camera.pack_cameras(copy.deepcopy(c), copy.deepcopy(s), copy.deepcopy(m), cfg['image_size'])
     assert torch.equal(f, e)
+
+
+def test_packed_table_cache_sees_in_place_edits_and_other_value_types():
+    """The fingerprint reads the bytes: a number edited IN PLACE inside a nested list, an
+    ndarray field or a centre array changes the table; ndarray / numpy-scalar fields and torch
+    centres (the per-item fallback of camera._blobs) are cached and watched just the same."""
+    import copy
+    import numpy as np
+    from tempo_amd import camera, synthetic as S
+    cfg = S.PANOPTIC
+    cams = S.ring_cameras(5, seed=4, target=cfg['space_center'])
+    c, s, m = S.frame_meta(cams, 3, cfg['raw_size'], cfg['image_size'])
+    m = copy.deepcopy(m)
+    camera.clear_cache()
+    a = camera.pack_cameras(c, s, m, cfg['image_size'])
+    assert camera.pack_cameras(c, s, m, cfg['image_size']) is a
+    m[1][2]['T'][0][0] += 25.0  # nested python list, edited in place
+    b = camera.pack_cameras(c, s, m, cfg['image_size'])
+    # (the frames of a recording share their calibration objects: view 2 changes in all)
+    assert b is not a and not torch.equal(b[1, 2], a[1, 2]) and torch.equal(b[:, 0], a[:, 0])
+    c[2][3][0] += 4.0  # ndarray centre, edited in place
+    d = camera.pack_cameras(c, s, m, cfg['image_size'])
+    assert d is not b and not torch.equal(d[2, 3], b[2, 3])
+    # ndarray fields and numpy scalars
+    for frame in m:
+        for cam in frame:
+            for k in list(cam):
+                if isinstance(cam[k], list):
+                    cam[k] = np.asarray(cam[k], dtype=np.float32)
+                elif isinstance(cam[k], float):
+                    cam[k] = np.float32(cam[k])
+    e = camera.pack_cameras(c, s, m, cfg['image_size'])
+    assert camera.pack_cameras(c, s, m, cfg['image_size']) is e
+    m[0][0]['R'][1, 1] += 0.125
+    f = camera.pack_cameras(c, s, m, cfg['image_size'])
+    assert f is not e and not torch.equal(f[0, 0], e[0, 0])
+    # torch centres
+    ct = [[torch.as_tensor(x) for x in row] for row in c]
+    g = camera.pack_cameras(ct, s, m, cfg['image_size'])
+    assert torch.equal(g, f) and camera.pack_cameras(ct, s, m, cfg['image_size']) is g
+    ct[0][1][1] += 2.0
+    h = camera.pack_cameras(ct, s, m, cfg['image_size'])
+    assert h is not g and not torch.equal(h[0, 1], g[0, 1])
+    camera.clear_cache()
