@@ -11,8 +11,22 @@ import torch
 from . import _lib, numerics
 
 
+_RAW_STREAM = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
+def _raw_stream(device):
+    """hipStream_t of torch's current stream on ``device`` as an int (0 = the null stream).
+    The raw accessor skips the Stream object: 0.3 instead of 4 us, several times per call."""
+    index = device.index
+    if index is None:
+        index = torch.cuda.current_device()
+    if _RAW_STREAM is not None:
+        return _RAW_STREAM(index)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 def _stream_ptr(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(_raw_stream(device))
 
 
 _STAGING = {}
@@ -37,7 +51,7 @@ def _staging(dev, numel):
     if numel * 4 > STAGING_MAX_BYTES or torch.cuda.is_current_stream_capturing():
         return torch.empty(numel, dtype=torch.float32, device=dev)
     key = (dev.index if dev.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(dev).cuda_stream)
+           _raw_stream(dev))
     buf = _STAGING.get(key)
     if buf is None or buf.numel() < numel:
         buf = None
