@@ -1,0 +1,118 @@
+"""Seeded random sweep of call shapes, HIP modules vs the CPU oracle: view counts 1..8, channel
+counts 1..40 (above 32 the module slices), odd map sizes, grids smaller than one wave and with
+awkward z extents, shared and per-item grid centres with skipped items, blob and noise maps,
+NCHW / channels_last / packed inputs.  Every case is small enough for the oracle to finish in
+well under a second.  Bars as everywhere: volume <= 1e-5 max-abs, NaN positions equal, mask /
+grids / offset bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import project_layer_ref as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _bits(bounding):
+    V = bounding.shape[-1]
+    return (bounding.to(torch.int32) << torch.arange(V, dtype=torch.int32)).sum(-1)
+
+
+def _close(got, ref):
+    assert got.shape == ref.shape
+    assert torch.equal(got.isnan(), ref.isnan())
+    return float((torch.nan_to_num(got) - torch.nan_to_num(ref)).abs().max())
+
+
+def _sizes(rng):
+    """(heatmap_size, image_size): the 2-D network's stride is 4 or 8, sizes need not be round"""
+    stride = int(rng.choice([4, 8]))
+    w, h = int(rng.randint(9, 70)), int(rng.randint(9, 50))
+    return [w, h], [w * stride, h * stride]
+
+
+def _root_spec(i):
+    rng = np.random.RandomState(9000 + i)
+    hm, img = _sizes(rng)
+    spec = dict(cfg='panoptic', B=int(rng.randint(1, 5)),
+                cube=[int(rng.randint(1, 22)), int(rng.randint(1, 22)), int(rng.randint(1, 27))],
+                hm=str(rng.choice(['blobs', 'noise'])), seed=9000 + i, hm_size=hm, img_size=img,
+                num_views=int(rng.randint(1, 9)),
+                num_joints=int(rng.choice([1, 3, 15, 16, 17, 20, 24, 31, 32, 33, 40])))
+    if rng.rand() < 0.4 and spec['B'] >= 2:
+        spec['centers'] = 'per_batch'
+    return spec, str(rng.choice(['nchw', 'channels_last', 'packed']))
+
+
+def _window_spec(i):
+    rng = np.random.RandomState(9500 + i)
+    hm, img = _sizes(rng)
+    # (cubic windows: the reference stacks the three face grids of a window into
+    # center_grid, project_layer.py:369-378, which needs equal face sizes)
+    sub_cube = [int(rng.randint(2, 19))] * 3
+    space = [float(rng.randint(1500, 2600)) for _ in range(3)]
+    spec = dict(cfg='panoptic', B=int(rng.randint(1, 6)), sub_cube=sub_cube,
+                hm=str(rng.choice(['blobs', 'noise'])), seed=9500 + i, hm_size=hm, img_size=img,
+                space=space, sub=[s / 2 for s in space], num_views=int(rng.randint(1, 9)),
+                num_joints=int(rng.choice([1, 4, 15, 17, 21, 32, 35])),
+                invalid_every=int(rng.choice([0, 2, 3])))
+    return spec, str(rng.choice(['nchw', 'channels_last']))
+
+
+def _as_layout(maps, layout):
+    import tempo_amd
+    from tempo_amd import ops
+    if layout == 'channels_last' and maps[0].shape[1] > 1:
+        return [m.contiguous(memory_format=torch.channels_last) for m in maps]
+    if layout == 'packed' and maps[0].shape[1] <= 32:
+        return tempo_amd.PackedHeatmaps(ops.repack_nhwc(maps), maps[0].shape[1])
+    return maps
+
+
+@pytest.mark.parametrize('i', range(24))
+def test_root_sweep(i, gpu_device):
+    import tempo_amd
+    spec, layout = _root_spec(i)
+    case = cases.build_root(None, full=spec)
+    ref_layer = O.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, ref_grids = ref_layer(*case['args'])
+    ref_mask = _bits(ref_layer.last_bounding)
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    layer.keep_mask = True
+    layer.keep_zmax = True
+    args = list(cases.to_device(case, gpu_device)['args'])
+    args[0] = _as_layout(args[0], layout)
+    with torch.no_grad():
+        cubes, grids = layer(*args)
+    torch.cuda.synchronize()
+    err = _close(cubes.cpu(), ref_cubes)
+    print(f'\n[root sweep {i}] {spec} {layout}: max-abs {err:.3e}')
+    assert err <= TOL
+    assert torch.equal(grids.cpu(), ref_grids)
+    assert torch.equal(layer.last_mask.cpu().to(torch.int32), ref_mask)
+    if layer.last_zmax is not None:
+        want = cubes.max(dim=4)[0]
+        assert torch.equal(torch.nan_to_num(layer.last_zmax, nan=-7.0),
+                           torch.nan_to_num(want, nan=-7.0))
+
+
+@pytest.mark.parametrize('i', range(16))
+def test_window_sweep(i, gpu_device):
+    import tempo_amd
+    spec, layout = _window_spec(i)
+    case = cases.build_window(None, full=spec)
+    ref_layer = O.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    ref_cubes, ref_off = ref_layer(*case['args'])
+    layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    args = list(cases.to_device(case, gpu_device)['args'])
+    args[0] = _as_layout(args[0], layout)
+    with torch.no_grad():
+        cubes, off = layer(*args)
+    torch.cuda.synchronize()
+    err = _close(cubes.cpu(), ref_cubes)
+    print(f'\n[window sweep {i}] {spec} {layout}: max-abs {err:.3e}')
+    assert err <= TOL
+    assert torch.equal(off.cpu(), ref_off)
+    assert torch.equal(layer.center_grid.cpu(), ref_layer.center_grid)
