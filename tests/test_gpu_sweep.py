@@ -116,3 +116,54 @@ def test_window_sweep(i, gpu_device):
     assert err <= TOL
     assert torch.equal(off.cpu(), ref_off)
     assert torch.equal(layer.center_grid.cpu(), ref_layer.center_grid)
+
+
+RTOL_GRAD = 2e-5  # tests/test_gpu_backward.py: fp32 atomics, order not fixed
+
+
+def _grad_check(got, ref, name):
+    scale = max(1.0, float(max(r.abs().max() for r in ref)))
+    worst = max(float((g.cpu() - r).abs().max()) for g, r in zip(got, ref))
+    print(f'\n[{name}] grad max-abs diff {worst:.3e} (scale {scale:.3e})')
+    assert worst <= RTOL_GRAD * scale
+    for g, r in zip(got, ref):  # texels no sample touches get exactly zero
+        assert int(((r == 0) & (g.cpu() != 0)).sum()) == 0
+
+
+@pytest.mark.parametrize('i', range(0, 24, 3))
+def test_root_backward_sweep(i, gpu_device):
+    """the same shapes through autograd: HIP backward vs torch autograd through the oracle"""
+    import tempo_amd
+    spec, _ = _root_spec(i)
+    case = cases.build_root(None, full=spec)
+    args = list(case['args'])
+    ref_fms = [f.clone().requires_grad_(True) for f in args[0]]
+    ref_cubes, _ = O.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')(
+        ref_fms, *args[1:])
+    weight = torch.randn(ref_cubes.shape, generator=torch.Generator().manual_seed(70 + i))
+    (torch.nan_to_num(ref_cubes) * weight).sum().backward()
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    fms = [f.clone().to(gpu_device).requires_grad_(True) for f in args[0]]
+    cubes, _ = layer(fms, *args[1:])
+    assert _close(cubes.detach().cpu(), ref_cubes.detach()) <= TOL
+    (torch.nan_to_num(cubes) * weight.to(gpu_device)).sum().backward()
+    _grad_check([f.grad for f in fms], [f.grad for f in ref_fms], f'root backward sweep {i}')
+
+
+@pytest.mark.parametrize('i', range(0, 16, 2))
+def test_window_backward_sweep(i, gpu_device):
+    import tempo_amd
+    spec, _ = _window_spec(i)
+    case = cases.build_window(None, full=spec)
+    args = list(case['args'])
+    ref_fms = [f.clone().requires_grad_(True) for f in args[0]]
+    ref_cubes, _ = O.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')(
+        ref_fms, *args[1:])
+    weight = torch.randn(ref_cubes.shape, generator=torch.Generator().manual_seed(80 + i))
+    (torch.nan_to_num(ref_cubes) * weight).sum().backward()
+    layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    fms = [f.clone().to(gpu_device).requires_grad_(True) for f in args[0]]
+    cubes, _ = layer(fms, args[1].to(gpu_device), *args[2:])
+    assert _close(cubes.detach().cpu(), ref_cubes.detach()) <= TOL
+    (torch.nan_to_num(cubes) * weight.to(gpu_device)).sum().backward()
+    _grad_check([f.grad for f in fms], [f.grad for f in ref_fms], f'window backward sweep {i}')
