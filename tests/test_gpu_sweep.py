@@ -167,3 +167,56 @@ def test_window_backward_sweep(i, gpu_device):
     assert _close(cubes.detach().cpu(), ref_cubes.detach()) <= TOL
     (torch.nan_to_num(cubes) * weight.to(gpu_device)).sum().backward()
     _grad_check([f.grad for f in fms], [f.grad for f in ref_fms], f'window backward sweep {i}')
+
+
+def _eq(a, b):
+    return torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+
+
+@pytest.mark.parametrize('i', range(24))
+def test_root_consumers_sweep(i, gpu_device):
+    """forward_zmax and zcolumns (no volume) equal the detector's expressions on the module's
+    own volume bit for bit, over the random shapes and layouts (center_net.py:230,
+    tempo_detector.py:204-206)."""
+    import tempo_amd
+    spec, layout = _root_spec(i)
+    case = cases.to_device(cases.build_root(None, full=spec), gpu_device)
+    args = list(case['args'])
+    args[0] = _as_layout(args[0], layout)
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+    with torch.no_grad():
+        cubes, _ = layer(*args)
+        zmax = layer.forward_zmax(*args)
+        B, C, X, Y, Z = cubes.shape
+        K = min(7, X * Y)
+        g = torch.Generator().manual_seed(400 + i)
+        index = torch.stack([torch.randperm(X * Y, generator=g)[:K] for _ in range(B)])
+        cols = layer.zcolumns(*args, index)
+    assert _eq(zmax, cubes.max(dim=4)[0])
+    idx = index.to(gpu_device).view(B, K, 1, 1).repeat(1, 1, C, Z)
+    want = torch.gather(torch.flatten(cubes, 2, 3).permute(0, 2, 1, 3), dim=1, index=idx)
+    assert _eq(cols, want)
+
+
+@pytest.mark.parametrize('i', range(16))
+def test_window_planes_sweep(i, gpu_device):
+    """get_planes (volume optional) equals torch.max over each axis of the module's volume
+    (tempo_pose.py:172-176), windows of every size: the generic epilogue, not only the fused
+    64^3 kernel."""
+    import tempo_amd
+    spec, layout = _window_spec(i)
+    case = cases.to_device(cases.build_window(None, full=spec), gpu_device)
+    args = list(case['args'])
+    args[0] = _as_layout(args[0], layout)
+    layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    with torch.no_grad():
+        cubes, off = layer(*args)
+        fms, grid_center = args[0], args[1]
+        centers, scales, cameras = args[6:9]
+        pxy, pxz, pyz, off2, none = layer.get_planes(fms, grid_center, centers, scales, cameras)
+        qxy, qxz, qyz, _, vol = layer.get_planes(fms, grid_center, centers, scales, cameras,
+                                                 want_cubes=True)
+    assert none is None and torch.equal(off, off2) and _eq(vol, cubes)
+    for p, q, dim in ((pxy, qxy, 4), (pxz, qxz, 3), (pyz, qyz, 2)):
+        want = cubes.max(dim=dim)[0]
+        assert _eq(p, want) and _eq(q, want)
