@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define TEMPO_ABI_VERSION 12
+#define TEMPO_ABI_VERSION 13
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
@@ -56,6 +56,10 @@ extern "C" {
 #define TEMPO_STATIC_SCRATCH_BYTES (64u << 20)
 #define TEMPO_MM_FMA 0
 #define TEMPO_MM_UNFUSED 7
+/* element types of tempo_repack_nhwc_half's inputs */
+#define TEMPO_DTYPE_F32 0
+#define TEMPO_DTYPE_F16 1
+#define TEMPO_DTYPE_BF16 2
 
 enum {
   TEMPO_OK = 0,
@@ -85,6 +89,18 @@ int tempo_padded_channels(int channels);
 int tempo_repack_nhwc(const void* const* views, int V, int B, int C_total,
                       int c_begin, int C, int H, int W, int CP, float* out,
                       void* stream);
+
+/* The same repack from 16-bit maps: `views` point to [B, C_total, H, W] tensors of
+ * IEEE half (dtype = TEMPO_DTYPE_F16) or bfloat16 (TEMPO_DTYPE_BF16); `out` is fp32 as above.
+ * Under mixed precision the reference's get_voxel converts its inputs with `.float()` first
+ * (@force_fp32(apply_to=('feature_maps', 'centers')), project_layer.py:65, :242); both
+ * conversions are exact, so the texels equal those of tempo_repack_nhwc on the converted
+ * tensors bit for bit and the fp32 copy is never made.  View pointers must be 2-byte
+ * aligned (TEMPO_E_ARG otherwise; 8-byte aligned planes take the wide path); any other
+ * dtype value: TEMPO_E_ARG. */
+int tempo_repack_nhwc_half(const void* const* views, int dtype, int V, int B,
+                           int C_total, int c_begin, int C, int H, int W, int CP,
+                           float* out, void* stream);
 
 /* Root-grid unprojection: ProjectLayer.get_voxel, project_layer.py:65-152
  * (agg_method == 'mean').

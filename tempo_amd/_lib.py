@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TEMPO_LIB') or os.path.join(_HERE, 'lib', 'libtempo_unproject.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _c_void_p, _c_int, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
@@ -20,6 +20,8 @@ SIGNATURES = {
     'tempo_padded_channels': (_c_int, [_c_int]),
     'tempo_repack_nhwc': (_c_int, [ctypes.POINTER(_c_void_p)] + [_c_int] * 8 +
                           [_c_void_p, _c_void_p]),
+    'tempo_repack_nhwc_half': (_c_int, [ctypes.POINTER(_c_void_p)] + [_c_int] * 9 +
+                               [_c_void_p, _c_void_p]),
     'tempo_unproject_root': (_c_int, [_c_void_p] * 5 + [_c_int] + [_c_void_p] * 4 +
                              [_c_int] * 10 + [_c_float] * 4 + [_c_int, _c_void_p]),
     'tempo_unproject_window': (_c_int, [_c_void_p] * 11 + [_c_int] * 13 +

@@ -1892,16 +1892,36 @@ struct RepackArgs {
 
 constexpr int kRepackPix = 64;
 
+// 16-bit maps (mixed-precision heads): DT = TEMPO_DTYPE_F16 / TEMPO_DTYPE_BF16.  The reference
+// converts them with `.float()` before sampling (@force_fp32, project_layer.py:65, :242); both
+// conversions are exact, so widening inside the repack gives the same texels without the
+// intermediate fp32 tensor (a third of the repack's traffic).
+template <int DT>
+__device__ __forceinline__ float widen16(unsigned short h) {
+  if (DT == TEMPO_DTYPE_F16) {
+    _Float16 f;
+    __builtin_memcpy(&f, &h, 2);
+    return (float)f;
+  }
+  return __uint_as_float((unsigned)h << 16);
+}
+
 // Generic tile: 64 pixels, scalar loads (any HW, any alignment).
+template <int DT = TEMPO_DTYPE_F32>
 __global__ __launch_bounds__(kThreads) void repack_kernel(const RepackArgs a) {
   __shared__ float s[TEMPO_MAX_CHANNELS][kRepackPix + 1];
   const int p0 = blockIdx.x * kRepackPix;
   const int v = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* in = a.views[v] + ((long long)(b + a.b0) * a.C_total + a.c_begin) * a.HW;
+  const long long first = ((long long)(b + a.b0) * a.C_total + a.c_begin) * a.HW;
+  const float* in = a.views[v] + first;
+  const unsigned short* in16 = reinterpret_cast<const unsigned short*>(a.views[v]) + first;
   for (int c = wave; c < a.CP; c += 4) {
     float val = 0.0f;
-    if (c < a.C && p0 + lane < a.HW) val = in[(long long)c * a.HW + p0 + lane];
+    if (c < a.C && p0 + lane < a.HW) {
+      const long long e = (long long)c * a.HW + p0 + lane;
+      val = DT == TEMPO_DTYPE_F32 ? in[e] : widen16<DT>(in16[e]);
+    }
     s[c][lane] = val;
   }
   __syncthreads();
@@ -1925,12 +1945,14 @@ __global__ __launch_bounds__(kThreads) void repack_kernel(const RepackArgs a) {
 constexpr int kWidePix = 256;
 constexpr int kWideStr = kWidePix + 2;
 
-template <int L>
+template <int L, int DT = TEMPO_DTYPE_F32>
 __device__ __forceinline__ void repack_wide_block(const RepackArgs& a, int bx, int v, int b,
                                                   float* s) {
   const int p0 = bx * kWidePix;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* in = a.views[v] + ((long long)(b + a.b0) * a.C_total + a.c_begin) * a.HW;
+  const long long first = ((long long)(b + a.b0) * a.C_total + a.c_begin) * a.HW;
+  const float* in = a.views[v] + first;
+  const unsigned short* in16 = reinterpret_cast<const unsigned short*>(a.views[v]) + first;
   const int p = p0 + 4 * lane;
   float4 r[L];
 #pragma unroll
@@ -1939,10 +1961,21 @@ __device__ __forceinline__ void repack_wide_block(const RepackArgs& a, int bx, i
     r[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (c < a.C && p < a.HW) {
       // read once: streaming policy, so the planes do not displace the chunk being gathered
-      typedef float f32x4 __attribute__((ext_vector_type(4)));
-      const f32x4 t = __builtin_nontemporal_load(
-          reinterpret_cast<const f32x4*>(in + (long long)c * a.HW + p));
-      r[k] = make_float4(t.x, t.y, t.z, t.w);
+      if (DT == TEMPO_DTYPE_F32) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 t = __builtin_nontemporal_load(
+            reinterpret_cast<const f32x4*>(in + (long long)c * a.HW + p));
+        r[k] = make_float4(t.x, t.y, t.z, t.w);
+      } else {
+        // 4 pixels = 8 bytes per lane (host-checked: 8-byte aligned planes)
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t t = __builtin_nontemporal_load(
+            reinterpret_cast<const u32x2_t*>(in16 + (long long)c * a.HW + p));
+        r[k] = make_float4(widen16<DT>((unsigned short)(t.x & 0xffffu)),
+                           widen16<DT>((unsigned short)(t.x >> 16)),
+                           widen16<DT>((unsigned short)(t.y & 0xffffu)),
+                           widen16<DT>((unsigned short)(t.y >> 16)));
+      }
     }
   }
 #pragma unroll
@@ -1967,16 +2000,16 @@ __device__ __forceinline__ void repack_wide_block(const RepackArgs& a, int bx, i
   }
 }
 
-template <int L>
+template <int L, int DT = TEMPO_DTYPE_F32>
 __global__ __launch_bounds__(kThreads) void repack_wide_kernel(const RepackArgs a) {
   __shared__ __attribute__((aligned(16))) float s[4 * L * kWideStr];
-  repack_wide_block<L>(a, blockIdx.x, blockIdx.y, blockIdx.z, s);
+  repack_wide_block<L, DT>(a, blockIdx.x, blockIdx.y, blockIdx.z, s);
 }
 
-template <int L>
+template <int L, int DT = TEMPO_DTYPE_F32>
 void launch_repack_wide(const RepackArgs& a, hipStream_t stream) {
   dim3 grid((a.HW + kWidePix - 1) / kWidePix, a.V, a.B);
-  hipLaunchKernelGGL((repack_wide_kernel<L>), grid, dim3(kThreads), 0, stream, a);
+  hipLaunchKernelGGL((repack_wide_kernel<L, DT>), grid, dim3(kThreads), 0, stream, a);
 }
 
 // The root tile kernel with the NEXT chunk's repack as its last workgroups (tempo_root_step):
@@ -2709,6 +2742,48 @@ int root_impl(const float* hm, const float* cam, const float* ax_x, const float*
                    num_groups, ex, stream);
 }
 
+// tempo_repack_nhwc / tempo_repack_nhwc_half: element type DT, everything else alike
+template <int DT>
+int repack_impl(const void* const* views, int V, int B, int C_total, int c_begin, int C, int H,
+                int W, int CP, float* out, void* stream) {
+  if (views == nullptr || out == nullptr) return TEMPO_E_NULL;
+  const int rc = check_common(V, C, CP, H, W);
+  if (rc != TEMPO_OK) return rc;
+  if (B <= 0 || B > 65535 || c_begin < 0 || c_begin + C > C_total) return TEMPO_E_DIM;
+  if (!aligned16(out)) return TEMPO_E_ARG;  // written with 128-bit stores
+  constexpr uintptr_t elem = DT == TEMPO_DTYPE_F32 ? 4 : 2;
+  RepackArgs a;
+  for (int v = 0; v < V; v++) {
+    if (views[v] == nullptr) return TEMPO_E_NULL;
+    if (reinterpret_cast<uintptr_t>(views[v]) % elem != 0) return TEMPO_E_ARG;
+    a.views[v] = static_cast<const float*>(views[v]);
+  }
+  for (int v = V; v < TEMPO_MAX_VIEWS; v++) a.views[v] = nullptr;
+  a.out = out;
+  a.V = V; a.B = B; a.C_total = C_total; a.c_begin = c_begin; a.C = C;
+  a.HW = H * W; a.CP = CP; a.b0 = 0;
+  // the wide tile reads 4 pixels per lane in one load (16 bytes of fp32, 8 of fp16 / bf16):
+  // every channel plane of every frame has to start on such a boundary
+  bool wide = a.HW % 4 == 0 && (((long long)C_total * a.HW) % 4 == 0) &&
+              (((long long)c_begin * a.HW) % 4 == 0);
+  for (int v = 0; v < V; v++)
+    wide = wide && (reinterpret_cast<uintptr_t>(views[v]) % (4 * elem) == 0);
+  if (wide) {
+    switch (CP / 4) {
+      case 4: launch_repack_wide<4, DT>(a, (hipStream_t)stream); break;
+      case 5: launch_repack_wide<5, DT>(a, (hipStream_t)stream); break;
+      case 6: launch_repack_wide<6, DT>(a, (hipStream_t)stream); break;
+      case 7: launch_repack_wide<7, DT>(a, (hipStream_t)stream); break;
+      case 8: launch_repack_wide<8, DT>(a, (hipStream_t)stream); break;
+      default: return TEMPO_E_PAD;
+    }
+  } else {
+    dim3 grid((a.HW + kRepackPix - 1) / kRepackPix, V, B);
+    hipLaunchKernelGGL(repack_kernel<DT>, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
+  }
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -2737,37 +2812,18 @@ int tempo_padded_channels(int channels) {
 
 int tempo_repack_nhwc(const void* const* views, int V, int B, int C_total, int c_begin,
                       int C, int H, int W, int CP, float* out, void* stream) {
-  if (views == nullptr || out == nullptr) return TEMPO_E_NULL;
-  const int rc = check_common(V, C, CP, H, W);
-  if (rc != TEMPO_OK) return rc;
-  if (B <= 0 || B > 65535 || c_begin < 0 || c_begin + C > C_total) return TEMPO_E_DIM;
-  if (!aligned16(out)) return TEMPO_E_ARG;  // written with 128-bit stores
-  RepackArgs a;
-  for (int v = 0; v < V; v++) {
-    if (views[v] == nullptr) return TEMPO_E_NULL;
-    a.views[v] = static_cast<const float*>(views[v]);
-  }
-  for (int v = V; v < TEMPO_MAX_VIEWS; v++) a.views[v] = nullptr;
-  a.out = out;
-  a.V = V; a.B = B; a.C_total = C_total; a.c_begin = c_begin; a.C = C;
-  a.HW = H * W; a.CP = CP; a.b0 = 0;
-  bool wide = a.HW % 4 == 0 && (((long long)C_total * a.HW) % 4 == 0) &&
-              (((long long)c_begin * a.HW) % 4 == 0);
-  for (int v = 0; v < V; v++) wide = wide && (reinterpret_cast<uintptr_t>(views[v]) % 16 == 0);
-  if (wide) {
-    switch (CP / 4) {
-      case 4: launch_repack_wide<4>(a, (hipStream_t)stream); break;
-      case 5: launch_repack_wide<5>(a, (hipStream_t)stream); break;
-      case 6: launch_repack_wide<6>(a, (hipStream_t)stream); break;
-      case 7: launch_repack_wide<7>(a, (hipStream_t)stream); break;
-      case 8: launch_repack_wide<8>(a, (hipStream_t)stream); break;
-      default: return TEMPO_E_PAD;
-    }
-  } else {
-    dim3 grid((a.HW + kRepackPix - 1) / kRepackPix, V, B);
-    hipLaunchKernelGGL(repack_kernel, grid, dim3(kThreads), 0, (hipStream_t)stream, a);
-  }
-  return (int)hipGetLastError();
+  return repack_impl<TEMPO_DTYPE_F32>(views, V, B, C_total, c_begin, C, H, W, CP, out, stream);
+}
+
+int tempo_repack_nhwc_half(const void* const* views, int dtype, int V, int B, int C_total,
+                           int c_begin, int C, int H, int W, int CP, float* out,
+                           void* stream) {
+  if (dtype == TEMPO_DTYPE_F16)
+    return repack_impl<TEMPO_DTYPE_F16>(views, V, B, C_total, c_begin, C, H, W, CP, out, stream);
+  if (dtype == TEMPO_DTYPE_BF16)
+    return repack_impl<TEMPO_DTYPE_BF16>(views, V, B, C_total, c_begin, C, H, W, CP, out,
+                                         stream);
+  return TEMPO_E_ARG;
 }
 
 int tempo_unproject_root(const float* hm, const float* cam, const float* ax_x,

@@ -95,8 +95,13 @@ def padded_channels(channels):
     return cp
 
 
+HALF_DTYPES = {torch.float16: 1, torch.bfloat16: 2}  # TEMPO_DTYPE_F16 / TEMPO_DTYPE_BF16
+
+
 def repack_nhwc(feature_maps, c_begin=0, channels=None, out=None):
-    """List of V fp32 ``[B,C,H,W]`` tensors -> ``[B,V,H,W,CP]`` channel-last."""
+    """List of V ``[B,C,H,W]`` tensors -> fp32 ``[B,V,H,W,CP]`` channel-last.  fp16 / bf16
+    maps (one dtype for all views) are widened inside the repack -- the reference's
+    ``@force_fp32`` without the fp32 copy; any other dtype goes through ``.float()``."""
     lib = _lib.load()
     V = len(feature_maps)
     fm0 = feature_maps[0]
@@ -104,10 +109,16 @@ def repack_nhwc(feature_maps, c_begin=0, channels=None, out=None):
     B, C_total, H, W = fm0.shape
     C = C_total - c_begin if channels is None else channels
     CP = padded_channels(C)
+    half = HALF_DTYPES.get(fm0.dtype, 0)
+    if half and any(fm.dtype != fm0.dtype for fm in feature_maps):
+        half = 0
     keep = []
     for i, fm in enumerate(feature_maps):
         if tuple(fm.shape) != (B, C_total, H, W):
             raise ValueError('feature maps of all views must share one shape')
+        if half:
+            keep.append(_need(fm.contiguous(), fm0.dtype, f'feature_maps[{i}]', dev))
+            continue
         if fm.dtype != torch.float32:
             fm = fm.float()  # the reference's force_fp32
         keep.append(_need(fm.contiguous(), torch.float32, f'feature_maps[{i}]', dev))
@@ -119,9 +130,13 @@ def repack_nhwc(feature_maps, c_begin=0, channels=None, out=None):
             raise ValueError('out has the wrong size')
     ptrs = (ctypes.c_void_p * V)(*[fm.data_ptr() for fm in keep])
     with torch.cuda.device(dev):
-        rc = lib.tempo_repack_nhwc(ptrs, V, B, C_total, c_begin, C, H, W, CP,
-                                   _ptr(out), _stream_ptr(dev))
-    _lib.check(rc, 'tempo_repack_nhwc')
+        if half:
+            rc = lib.tempo_repack_nhwc_half(ptrs, half, V, B, C_total, c_begin, C, H, W, CP,
+                                            _ptr(out), _stream_ptr(dev))
+        else:
+            rc = lib.tempo_repack_nhwc(ptrs, V, B, C_total, c_begin, C, H, W, CP,
+                                       _ptr(out), _stream_ptr(dev))
+    _lib.check(rc, 'tempo_repack_nhwc_half' if half else 'tempo_repack_nhwc')
     return out
 
 
@@ -411,7 +426,10 @@ def root_step(feature_maps, cam, axes, heatmap_size, image_size, c_begin=0, chan
         _need(zmax_out, torch.float32, 'zmax_out', dev)
         if tuple(zmax_out.shape) != (B, C, X, Y):
             raise ValueError(f'zmax_out must be [{B},{C},{X},{Y}]')
-    if in_library:  # the same chunk loop inside the library: one call, no per-chunk host work
+    # (16-bit maps: the library's step reads fp32 tensors; the chunk loop below widens them
+    # chunk by chunk inside the repack instead of converting the whole batch first)
+    all_half = fm0.dtype in HALF_DTYPES and all(fm.dtype == fm0.dtype for fm in feature_maps)
+    if in_library and not all_half:  # the chunk loop inside the library: one call
         return _root_step_library(feature_maps, cam, axes, heatmap_size, image_size, c_begin, C,
                                 live, out, grids, mask, mm_mode, chunk, hm_buf, zmax_out)
     if B <= chunk:

@@ -67,6 +67,15 @@ def test_bad_arguments_are_rejected_before_any_launch():
     ptrs = (ctypes.c_void_p * 2)(16, 16)
     assert lib.tempo_repack_nhwc(ptrs, 2, 1, 15, 0, 15, 8, 8, 16, None, None) == -1
     assert lib.tempo_repack_nhwc(ptrs, 2, 1, 15, 4, 15, 8, 8, 16, one, None) == -2
+    # the 16-bit repack: dtype 1 (fp16) or 2 (bf16) only, pointers 2-byte aligned
+    half = lambda dtype, **kw: lib.tempo_repack_nhwc_half(
+        kw.get('ptrs', ptrs), dtype, 2, 1, 15, kw.get('c0', 0), 15, 8, 8, kw.get('CP', 16),
+        kw.get('out', one), None)
+    assert half(0) == -5 and half(3) == -5 and half(-1) == -5
+    assert half(1, out=None) == -1 and half(2, c0=4) == -2 and half(1, CP=12) == -3
+    assert half(1, ptrs=(ctypes.c_void_p * 2)(16, 17)) == -5
+    assert half(2, ptrs=(ctypes.c_void_p * 2)(16, None)) == -1
+    assert half(1, out=ctypes.c_void_p(24)) == -5  # out is written with 128-bit stores
     assert lib.tempo_project_points(one, one, 0, 5, 1., 1., 1., 1., 0, one, one, one, None) == -2
 
 

@@ -54,3 +54,40 @@ def test_window_half_maps_forward_and_backward(dtype, gpu_device):
         assert h.grad is not None and h.grad.dtype == dtype
         assert torch.equal(h.grad, f.grad.to(dtype))
     assert any(float(f.grad.abs().max()) > 0 for f in full)
+
+
+@pytest.mark.parametrize('dtype', [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape,c_begin,channels', [
+    ((3, 15, 12, 20), 0, None),    # wide tile (HW % 4 == 0, aligned planes)
+    ((2, 40, 16, 24), 32, 8),      # channel slice of a wider tensor, wide tile
+    ((2, 17, 9, 7), 0, None),      # HW = 63: the generic tile
+    ((2, 21, 11, 13), 4, 17),      # generic tile, slice, CP = 20
+    ((1, 32, 8, 520), 0, None),    # more than one 256-pixel tile per row of tiles, CP = 32
+])
+def test_half_repack_equals_the_repack_of_the_converted_maps(dtype, shape, c_begin, channels,
+                                                             gpu_device):
+    """tempo_repack_nhwc_half widens inside the repack: texels bit-equal to tempo_repack_nhwc
+    on ``.float()`` of the same maps, padding channels zero; special values included."""
+    from tempo_amd import ops
+    g = torch.Generator().manual_seed(sum(shape) + c_begin)
+    maps = []
+    for v in range(3):
+        m = (torch.rand(*shape, generator=g) * 4 - 2).to(dtype)
+        m.view(-1)[:6] = torch.tensor([0.0, -0.0, float('inf'), float('-inf'), float('nan'),
+                                       6e-8], dtype=dtype)  # (6e-8: a half denormal)
+        maps.append(m.to(gpu_device))
+    got = ops.repack_nhwc(maps, c_begin, channels)
+    want = ops.repack_nhwc([m.float() for m in maps], c_begin, channels)
+    assert got.dtype == torch.float32 and got.shape == want.shape
+    assert torch.equal(got.view(torch.int32), want.view(torch.int32))
+    C = shape[1] - c_begin if channels is None else channels
+    assert not got[..., C:].any()
+    # an odd view pointer offset (2-byte aligned only) goes through the generic tile
+    flat = torch.zeros(maps[0].numel() + 1, dtype=dtype, device=gpu_device)
+    shifted = []
+    for m in maps:
+        buf = flat.clone()
+        buf[1:] = m.reshape(-1)
+        shifted.append(buf[1:].view(shape))
+    assert torch.equal(ops.repack_nhwc(shifted, c_begin, channels).view(torch.int32),
+                       want.view(torch.int32))
