@@ -18,6 +18,8 @@ Differences, all deliberate:
   reference would hit a ``NameError``: ``FisheyeCameraTorch`` is undefined).
 * an error in sampling raises instead of dropping into ``pdb`` (``:285-286``).
 """
+import warnings
+
 import torch
 import torch.nn as nn
 
@@ -148,6 +150,24 @@ def _batch_channels(feature_maps):
     return int(feature_maps[0].shape[0]), int(feature_maps[0].shape[1])
 
 
+def _alert_not_deterministic():
+    """The backward kernels add each texel's contributions with fp32 atomics, in no fixed
+    order: last-bit differences between runs.  So does the op they replace --
+    ``grid_sampler_2d_backward_cuda`` of ``F.grid_sample`` (project_layer.py:128-133, :278-284)
+    -- and torch reports it under ``torch.use_deterministic_algorithms``: an error, or a warning
+    with ``warn_only=True``.  Same behaviour here."""
+    if not torch.are_deterministic_algorithms_enabled():
+        return
+    msg = ('tempo_amd unprojection backward does not have a deterministic implementation '
+           '(fp32 atomic adds into the heatmap gradient), like grid_sampler_2d_backward_cuda '
+           'which it replaces; torch.use_deterministic_algorithms(True, warn_only=True) turns '
+           'this error into a warning')
+    if torch.is_deterministic_algorithms_warn_only_enabled():
+        warnings.warn(msg)
+    else:
+        raise RuntimeError(msg)
+
+
 class _Unproject(torch.autograd.Function):
     """Differentiable unprojection (root or window): the forward records the clamp
     mask, the backward scatters the volume's gradient into the heatmaps
@@ -194,6 +214,7 @@ class _Unproject(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_cubes):
+        _alert_not_deterministic()
         meta = ctx.meta
         B, C, H, W = ctx.fm_shape
         dev = grad_cubes.device

@@ -331,3 +331,36 @@ def test_window_backward_many_views(gpu_device):
     cubes, _ = layer(fms, args[1].to(gpu_device), *args[2:])
     (cubes * weight.to(gpu_device)).sum().backward()
     _grads_close([f.grad for f in fms], [f.grad for f in ref_fms], 'window V=13')
+
+
+def test_backward_reports_nondeterminism_like_grid_sample(gpu_device):
+    """torch.use_deterministic_algorithms(True): the op this backward replaces
+    (grid_sampler_2d_backward_cuda) raises, or warns with warn_only; so does the HIP one."""
+    import warnings
+    import tempo_amd
+    spec = dict(cfg='panoptic', B=1, cube=[8, 8, 4], hm='noise', seed=901)
+    case = cases.build_root(None, full=spec)
+    args = list(case['args'])
+    layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
+
+    def loss():
+        fms = _leafs(args[0], gpu_device)
+        return layer(fms, *args[1:])[0].sum(), fms
+
+    try:
+        torch.use_deterministic_algorithms(True)
+        out, _ = loss()  # the forward is deterministic
+        with pytest.raises(RuntimeError, match='deterministic'):
+            out.backward()
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        out, fms = loss()
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter('always')
+            out.backward()
+        assert any('deterministic' in str(w.message) for w in seen)
+        assert fms[0].grad is not None and float(fms[0].grad.abs().max()) > 0
+    finally:
+        torch.use_deterministic_algorithms(False)
+    out, fms = loss()
+    out.backward()
+    assert fms[0].grad is not None
