@@ -791,7 +791,7 @@ def module_timing(args, wl, dev):
             'what': 'tempo_amd.ProjectLayer.forward(list of [B,C,H,W], ..., lists of dicts), '
                     'host-synchronised wall time incl. camera packing; grids not materialised; '
                     'pipelined_ms = 50 calls back to back, one synchronisation (host_ms of it '
-                    'is python: argument checks, the identity-keyed camera-table cache)'}
+                    'is python: argument checks, the content-keyed camera-table cache)'}
 
 
 def main():

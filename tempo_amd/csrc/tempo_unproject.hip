@@ -1884,7 +1884,7 @@ __global__ __launch_bounds__(kThreads) void unrepack_kernel(const UnrepackArgs a
 
 // ------------------------------------------------------------------ repack
 struct RepackArgs {
-  const float* views[TEMPO_MAX_VIEWS];
+  const void* views[TEMPO_MAX_VIEWS];  // fp32, or fp16 / bf16 for the DT instantiations
   float* out;
   int V, B, C_total, c_begin, C, HW, CP;
   int b0;  // first frame of the source tensors to take (out is numbered from 0)
@@ -1914,8 +1914,8 @@ __global__ __launch_bounds__(kThreads) void repack_kernel(const RepackArgs a) {
   const int v = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long first = ((long long)(b + a.b0) * a.C_total + a.c_begin) * a.HW;
-  const float* in = a.views[v] + first;
-  const unsigned short* in16 = reinterpret_cast<const unsigned short*>(a.views[v]) + first;
+  const float* in = static_cast<const float*>(a.views[v]) + first;
+  const unsigned short* in16 = static_cast<const unsigned short*>(a.views[v]) + first;
   for (int c = wave; c < a.CP; c += 4) {
     float val = 0.0f;
     if (c < a.C && p0 + lane < a.HW) {
@@ -1951,8 +1951,8 @@ __device__ __forceinline__ void repack_wide_block(const RepackArgs& a, int bx, i
   const int p0 = bx * kWidePix;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long long first = ((long long)(b + a.b0) * a.C_total + a.c_begin) * a.HW;
-  const float* in = a.views[v] + first;
-  const unsigned short* in16 = reinterpret_cast<const unsigned short*>(a.views[v]) + first;
+  const float* in = static_cast<const float*>(a.views[v]) + first;
+  const unsigned short* in16 = static_cast<const unsigned short*>(a.views[v]) + first;
   const int p = p0 + 4 * lane;
   float4 r[L];
 #pragma unroll
@@ -2756,7 +2756,7 @@ int repack_impl(const void* const* views, int V, int B, int C_total, int c_begin
   for (int v = 0; v < V; v++) {
     if (views[v] == nullptr) return TEMPO_E_NULL;
     if (reinterpret_cast<uintptr_t>(views[v]) % elem != 0) return TEMPO_E_ARG;
-    a.views[v] = static_cast<const float*>(views[v]);
+    a.views[v] = views[v];
   }
   for (int v = V; v < TEMPO_MAX_VIEWS; v++) a.views[v] = nullptr;
   a.out = out;
@@ -3111,7 +3111,7 @@ int root_step_impl(const void* const* views, int C_total, int c_begin, const flo
     if (fuse && b0 + chunk < B) {  // the next chunk, into the other half
       const int b1 = b0 + chunk;
       for (int v = 0; v < TEMPO_MAX_VIEWS; v++)
-        tail.views[v] = v < V ? static_cast<const float*>(views[v]) : nullptr;
+        tail.views[v] = v < V ? views[v] : nullptr;
       tail.out = workspace + ((ci & 1) ? 0 : half);
       tail.V = V; tail.B = b1 + chunk <= B ? chunk : B - b1;
       tail.C_total = C_total; tail.c_begin = c_begin; tail.C = C;
