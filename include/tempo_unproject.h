@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define TEMPO_ABI_VERSION 13
+#define TEMPO_ABI_VERSION 14
 #define TEMPO_CAM_FLOATS 32
 #define TEMPO_MAX_VIEWS 32
 #define TEMPO_MAX_CHANNELS 32 /* per call; wider tensors go in channel slices */
@@ -412,6 +412,47 @@ int tempo_unproject_window_backward(const float* grad_cubes, const float* cam,
                                     int FX, int FY, int FZ, int VX, int VY, int VZ,
                                     float hm_w, float hm_h, float img_w, float img_h,
                                     int mm_unfused, int tile_texels, void* stream);
+
+/* Training THROUGH the fused window planes: the pose regressor takes torch.max of the window
+ * volume over z, y and x (tempo_pose.py:172-176) inside forward_train (freeze_2d = False),
+ * so autograd sends each plane entry's gradient to one voxel of the volume -- the first one
+ * along the reduced axis that attains the maximum (CPU torch.max; a NaN, once met, is the
+ * maximum) -- through torch.clamp's backward (gradient passes where 0 <= x <= 1) and the
+ * masked mean into the heatmaps (project_layer.py:278-378).  These two calls do that without
+ * the [NW, C, VX, VY, VZ] volume and its gradient volume ever existing:
+ *
+ * tempo_window_planes_claims: given the FINAL planes of tempo_unproject_window_planes on the
+ *   same inputs (plane_xy [NW,C,VX,VY], plane_xz [NW,C,VX,VZ], plane_yz [NW,C,VY,VZ]),
+ *   recompute every voxel and record per plane entry the claim of the voxel its gradient
+ *   goes to: int32 claim_* in the planes' layouts, 2 * (index along the reduced axis) + 1 if
+ *   the clamp blocks the gradient there.  Entries of skipped windows keep 0x7f7f7f7f.
+ *   hm is the repacked [F, V, H, W, CP] buffer; every other argument as
+ *   tempo_unproject_window_planes.  All six plane / claim pointers are required.
+ *
+ * tempo_unproject_window_planes_backward: grad_xy / grad_xz / grad_yz (the planes'
+ *   incoming gradients, fp32, planes' layouts) + those claims -> grad_hm [F, V, H, W, CP]
+ *   (zeroed, then accumulated with fp32 atomics like tempo_unproject_window_backward, whose
+ *   kernel it shares; tile_texels as there).  Maps wider or taller than 16384 texels:
+ *   TEMPO_E_SIZE.  Follow with tempo_unrepack_nchw for per-view NCHW gradients. */
+int tempo_window_planes_claims(const float* hm, const float* cam,
+                               const int32_t* win_frame, const float* fx,
+                               const float* fy, const float* fz, const int32_t* tl,
+                               const int32_t* start, const int32_t* end,
+                               const uint8_t* live, const float* plane_xy,
+                               const float* plane_xz, const float* plane_yz,
+                               int32_t* claim_xy, int32_t* claim_xz, int32_t* claim_yz,
+                               int NW, int F, int V, int C, int CP, int H, int W,
+                               int FX, int FY, int FZ, int VX, int VY, int VZ,
+                               float hm_w, float hm_h, float img_w, float img_h,
+                               int mm_unfused, void* stream);
+int tempo_unproject_window_planes_backward(
+    const float* grad_xy, const float* grad_xz, const float* grad_yz,
+    const int32_t* claim_xy, const int32_t* claim_xz, const int32_t* claim_yz,
+    const float* cam, const int32_t* win_frame, const float* fx, const float* fy,
+    const float* fz, const int32_t* tl, const int32_t* start, const int32_t* end,
+    const uint8_t* live, float* grad_hm, int NW, int F, int V, int C, int CP, int H,
+    int W, int FX, int FY, int FZ, int VX, int VY, int VZ, float hm_w, float hm_h,
+    float img_w, float img_h, int mm_unfused, int tile_texels, void* stream);
 
 /* Inverse of tempo_repack_nhwc: channel-last [B, V, H, W, CP] -> channels
  * [c_begin, c_begin + C) of V per-view fp32 [B, C_total, H, W] tensors

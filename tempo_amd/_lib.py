@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TEMPO_LIB') or os.path.join(_HERE, 'lib', 'libtempo_unproject.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _c_void_p, _c_int, _c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 
@@ -44,6 +44,10 @@ SIGNATURES = {
                                       [_c_int] * 9 + [_c_float] * 4 + [_c_int, _c_void_p]),
     'tempo_unproject_window_backward': (_c_int, [_c_void_p] * 12 + [_c_int] * 13 +
                                         [_c_float] * 4 + [_c_int, _c_int, _c_void_p]),
+    'tempo_window_planes_claims': (_c_int, [_c_void_p] * 16 + [_c_int] * 13 +
+                                   [_c_float] * 4 + [_c_int, _c_void_p]),
+    'tempo_unproject_window_planes_backward': (_c_int, [_c_void_p] * 16 + [_c_int] * 13 +
+                                               [_c_float] * 4 + [_c_int, _c_int, _c_void_p]),
     'tempo_unrepack_nchw': (_c_int, [_c_void_p, ctypes.POINTER(_c_void_p)] + [_c_int] * 8 +
                             [_c_void_p]),
     'tempo_root_step_workspace': (ctypes.c_longlong, [_c_int] * 6),

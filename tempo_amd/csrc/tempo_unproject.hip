@@ -147,6 +147,13 @@ struct UnprojArgs {
   float* col_out;
   int K;
   unsigned plane_bytes;
+  // Trainable axis-max planes (window): per plane entry the CLAIM of the voxel torch.max
+  // routes the entry's gradient to = 2 * (index along the reduced axis of the FIRST voxel
+  // that attains the maximum) + 1 if the clamp blocks that voxel's gradient; laid out like
+  // the planes (pl01 / pl02 / pl12).  window_claim_kernel writes them (atomic minimum, from
+  // 0x7f7f7f7f), the backward reads them together with the planes' incoming gradients.
+  int32_t* claim[3];
+  const float* gplane[3];
 };
 
 __device__ __forceinline__ int slot_view(const UnprojArgs& a, int slot) {
@@ -471,6 +478,8 @@ __device__ __forceinline__ bool voxel_world(const UnprojArgs& a, int b, int n,
 // pattern of channel 4 cq + j of voxel s * VPS + vq (lane = vq * L + cq), clamped, -0.0 as
 // +0.0, so that the patterns order like the values with NaN on top (0 for slots that hold no
 // voxel) -- and write the LDS tile only if the volume is asked for (a.cubes).
+// KEEP == 2: the LDS tile holds the mean BEFORE the clamp (window_claim_kernel applies the
+// clamp itself, because it also needs to know where the clamp blocks the gradient).
 template <int MODE, int L, int SB, int UNF, int KEEP = 0>
 __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int frame, int n0,
                                                int lane, unsigned char* wbase,
@@ -723,6 +732,22 @@ __device__ __forceinline__ void unproject_wave(const UnprojArgs& a, int b, int f
   // exact division; a NaN anywhere in the wave (torch.clamp keeps it) sends the whole
   // wave through the NaN-aware clamp
   const bool slow = normalise_tile<NSUB>(acc01, acc23, dr);
+  if (KEEP == 2) {
+#pragma unroll
+    for (int s = 0; s < NSUB; s++) {
+      const int vsl = s * VPS + vq;
+      if (lane_on && vsl < kWaveVox) {
+        float* o = s_out + (4 * cq) * TSTR + vsl;
+        o[0 * TSTR] = acc01[s].x;
+        o[1 * TSTR] = acc01[s].y;
+        o[2 * TSTR] = acc23[s].x;
+        o[3 * TSTR] = acc23[s].y;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return;
+  }
   if (a.cmask != nullptr) {
     // torch.clamp's backward passes the gradient where min <= x <= max (NaN: no)
     unsigned long long* mw =
@@ -930,6 +955,104 @@ __global__ __launch_bounds__(kTileWaves * 64) void unproject_columns_kernel(cons
   const float* s_out = reinterpret_cast<const float*>(wbase);
   if (mine)
     for (int ch = 0; ch < a.C; ch++) dst[ch * Z] = s_out[ch * TSTR + lane];
+}
+
+// ------------------------------- window: which voxel does each plane entry's gradient go to?
+// Training through the fused planes (tempo_pose.py:172-176 takes torch.max of the window volume
+// over z, y and x): autograd sends a plane entry's gradient to ONE voxel of its line -- the
+// first that attains the maximum (CPU torch.max; once a NaN is met it is the maximum) -- and
+// torch.clamp's backward lets it through only if that voxel's mean was inside [0, 1].  With
+// the FINAL planes given, this kernel recomputes every voxel's mean (unproject_wave, the same
+// arithmetic as the kernel that made the planes), and a voxel whose clamped value equals its
+// line's maximum files a claim, 2 * index + blocked, by atomic minimum: the smallest index
+// wins, and its own blocked bit with it.
+// Windows of 64 voxels along z make a wave one z-column: its claims for the xy plane all go
+// to one word and are reduced inside the wave first.
+template <int L, int UNF>
+__global__ __launch_bounds__(kTileWaves * 64) void window_claim_kernel(const UnprojArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int SB = L >= 7 ? 2 : TEMPO_SB_WINDOW;
+  const int run = blockIdx.x >> 3;
+  const int item = (blockIdx.x & 7) * a.chunk + run;
+  if (run >= a.chunk || item >= a.total) return;
+  const int b = __builtin_amdgcn_readfirstlane(item / a.tiles);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = (item - b * a.tiles) * a.tile_vox + wave * a.wave_vox;
+  if (n0 >= a.N) return;
+  unsigned char* wbase = smem + (size_t)wave * wave_lds_bytes(L);
+  int frame = b;
+  if (a.win_frame != nullptr) frame = uniform_load(a.win_frame, b);
+  // a skipped window's volume is constant zero: whatever voxel its entries point at, the
+  // backward adds nothing for it, so its claims are left alone
+  if ((a.live != nullptr && uniform_load_u8(a.live, b) == 0) || (unsigned)frame >= (unsigned)a.F)
+    return;
+  unproject_wave<MODE_WINDOW, L, SB, UNF, 2>(a, b, frame, n0, lane, wbase);
+  constexpr int TSTR = kWaveVox + 1;
+  const float* s_out = reinterpret_cast<const float*>(wbase);
+  const int n = n0 + lane;
+  const bool mine = lane < a.wave_vox && n < a.N;
+  int i0 = 0, i1 = 0, i2 = 0;
+  if (mine) voxel_index(a, n, &i0, &i1, &i2);
+  const int d0 = a.dim[0], d1 = a.dim[1], d2 = a.dim[2];
+  const bool column = d2 == kWaveVox;  // the wave is one z-column: one xy entry per channel
+  // The maxima of a few channels at a time, their loads in flight together: one round trip
+  // to the L2 per group instead of one per channel and plane (a chain of dependent misses
+  // otherwise), without holding all 3 x 16 values (136 VGPRs, 3 waves per SIMD, when all
+  // channels were loaded at once).  32-bit element offsets from one base per plane.
+  constexpr int G = 4;
+  const unsigned* q01 = a.pl01 + (long long)b * a.C * d0 * d1;
+  const unsigned* q02 = a.pl02 + (long long)b * a.C * d0 * d2;
+  const unsigned* q12 = a.pl12 + (long long)b * a.C * d1 * d2;
+  int32_t* k01 = a.claim[0] + (long long)b * a.C * d0 * d1;
+  int32_t* k02 = a.claim[1] + (long long)b * a.C * d0 * d2;
+  int32_t* k12 = a.claim[2] + (long long)b * a.C * d1 * d2;
+  const int s01 = d0 * d1, s02 = d0 * d2, s12 = d1 * d2;  // (C * N * 4 < 2^36, s* < 2^31 / 4)
+  const int o01 = mine ? i0 * d1 + i1 : 0, o02 = mine ? i0 * d2 + i2 : 0;
+  const int o12 = mine ? i1 * d2 + i2 : 0;
+  // A maximum of exactly 0 is attained by every voxel of its line (clamped values are >= 0),
+  // so its first voxel holds the claim and nobody else needs to file one: with real
+  // heatmaps (mostly zero) that is nearly every line.  Other ties are rare; their claims
+  // simply race to the minimum.  No claim is read back here: fire-and-forget atomics.
+  auto file = [&](int32_t* claim, int word) { atomicMin(claim, word); };
+#pragma unroll 1
+  for (int c0 = 0; c0 < a.C; c0 += G) {
+    unsigned m01[G], m02[G], m12[G];
+    float raw[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const int ch = c0 + g < a.C ? c0 + g : c0;  // (the tail group repeats its first channel)
+      m01[g] = q01[(long long)ch * s01 + o01];
+      m02[g] = q02[(long long)ch * s02 + o02];
+      m12[g] = q12[(long long)ch * s12 + o12];
+      raw[g] = s_out[ch * TSTR + lane];
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+      const int ch = c0 + g;
+      if (ch >= a.C) continue;  // (wave-uniform)
+      const bool isnan = raw[g] != raw[g];
+      const float v = isnan ? raw[g] : fminf(fmaxf(raw[g], 0.0f), 1.0f);
+      const int blocked = (raw[g] >= 0.0f && raw[g] <= 1.0f) ? 0 : 1;
+      auto hit = [&](unsigned bits, int index) {
+        const float m = __uint_as_float(bits);
+        return mine && (v == m || (isnan && m != m)) && (m != 0.0f || index == 0);
+      };
+      const bool h01 = hit(m01[g], i2);
+      if (column) {
+        // the wave IS the line: the minimum over its lanes is the claim, stored plainly
+        // (unsigned maximum of the complement = minimum; lanes without a claim offer 0)
+        const unsigned w = h01 ? ~(unsigned)((i2 << 1) | blocked) : 0u;
+        const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)wave_umax_to_lane63(w), 63);
+        if (m != 0u && lane == 0) k01[(long long)ch * s01 + o01] = (int)~m;
+      } else if (h01) {
+        file(k01 + (long long)ch * s01 + o01, (i2 << 1) | blocked);
+      }
+      if (hit(m02[g], i1)) file(k02 + (long long)ch * s02 + o02, (i1 << 1) | blocked);
+      if (hit(m12[g], i0)) file(k12 + (long long)ch * s12 + o12, (i0 << 1) | blocked);
+    }
+  }
 }
 
 // --------------------------------------------- window + axis-max planes, fused
@@ -1618,7 +1741,11 @@ constexpr BrickLds brick_lds(int L, int cap) {
   return l;
 }
 
-template <int L, int UNF, int CAP>
+// PLN: the incoming gradient is that of the three axis-max planes (a.gplane), routed to the
+// voxels that hold the planes' claims (a.claim, window_claim_kernel), instead of a gradient
+// volume with the forward's clamp mask.  Most bricks then carry no gradient at all (the
+// claimed voxels are a quarter of a window's, in two thirds of its bricks) and leave early.
+template <int L, int UNF, int CAP, int PLN = 0>
 __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojArgs a) {
   constexpr int MODE = MODE_WINDOW;
   constexpr int VPS = 64 / L;
@@ -1662,7 +1789,52 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
   // the forward's clamp blocks it, parked as [channel][voxel]
   float x = 0.f, y = 0.f, z = 0.f;
   bool have = false;
-  {
+  if (PLN) {
+    const float den = (float)a.V + 1e-6f;
+    const int d0 = a.dim[0], d1 = a.dim[1], d2 = a.dim[2];
+    // all claims first (unconditional loads, in flight together), then the few gradients
+    // they select.  (A blocked claim is odd and matches no index; the sum runs z, y, x: the
+    // order autograd accumulates the three torch.max backwards in does not reach fp32 here
+    // -- a voxel holding two claims of one channel is rare.)
+    const int j0 = inb ? i0 : 0, j1 = inb ? i1 : 0, j2 = inb ? i2 : 0;
+    const long long s01 = (long long)d0 * d1, s02 = (long long)d0 * d2, s12 = (long long)d1 * d2;
+    const long long p01 = ((long long)b * a.C * d0 + j0) * d1 + j1;
+    const long long p02 = ((long long)b * a.C * d0 + j0) * d2 + j2;
+    const long long p12 = ((long long)b * a.C * d1 + j1) * d2 + j2;
+    // (claims AND gradients unconditionally, all in flight together: one round trip.  The
+    // LDS tile limits this kernel to 3 waves per SIMD, so the 6 x CP registers are free.)
+    int c01[CP], c02[CP], c12[CP];
+    float g01[CP], g02[CP], g12[CP];
+#pragma unroll
+    for (int ch = 0; ch < CP; ch++) {
+      const int cc = ch < a.C ? ch : 0;
+      c01[ch] = a.claim[0][p01 + cc * s01];
+      c02[ch] = a.claim[1][p02 + cc * s02];
+      c12[ch] = a.claim[2][p12 + cc * s12];
+      g01[ch] = a.gplane[0][p01 + cc * s01];
+      g02[ch] = a.gplane[1][p02 + cc * s02];
+      g12[ch] = a.gplane[2][p12 + cc * s12];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float gv[CP];
+    bool any = false;
+#pragma unroll
+    for (int ch = 0; ch < CP; ch++) {
+      gv[ch] = 0.0f;
+      if (inb && ch < a.C) {
+        if (c01[ch] == (i2 << 1)) gv[ch] += g01[ch];
+        if (c02[ch] == (i1 << 1)) gv[ch] += g02[ch];
+        if (c12[ch] == (i0 << 1)) gv[ch] += g12[ch];
+        any = any || gv[ch] != 0.0f;
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(any) == 0) return;  // nothing to send back from this brick
+    for (int i = lane; i < CAP * CP; i += 64) tile[i] = 0.0f;
+    have = inb && voxel_world<MODE>(a, b, n, &x, &y, &z);
+    if (__builtin_amdgcn_ballot_w64(have) == 0) return;
+#pragma unroll
+    for (int ch = 0; ch < CP; ch++) st[ch * TSTR + lane] = gv[ch] / den;
+  } else {
     const float* gout = a.cubes + (long long)b * a.C * a.N;
     const float den = (float)a.V + 1e-6f;
     // the forward's mask layout: tile n >> 6, word [s * 4 + j], bit vq * L + cq
@@ -2453,7 +2625,7 @@ int launch_backward_one(const UnprojArgs& a, hipStream_t stream) {
 }
 
 // window backward through the LDS tile (window_backward_brick_kernel)
-template <int L, int UNF, int CAP>
+template <int L, int UNF, int CAP, int PLN = 0>
 int launch_backward_brick(const UnprojArgs& a, hipStream_t stream) {
   UnprojArgs k = a;
   fill_order_magic(k.order, k.magic, a.V, a.dim);
@@ -2466,9 +2638,65 @@ int launch_backward_brick(const UnprojArgs& a, hipStream_t stream) {
   k.tiles = (int)bricks;
   k.total = (int)total;
   k.chunk = (k.total + 7) / 8;
-  hipLaunchKernelGGL((window_backward_brick_kernel<L, UNF, CAP>), dim3(8 * k.chunk), dim3(64),
+  hipLaunchKernelGGL((window_backward_brick_kernel<L, UNF, CAP, PLN>), dim3(8 * k.chunk), dim3(64),
                      (size_t)brick_lds(L, CAP).total, stream, k);
   return (int)hipGetLastError();
+}
+
+// the planes-gradient backward (window_backward_brick_kernel<.., PLN = 1>): the brick kernel
+// only -- there is no gradient volume the per-sample kernel could read
+int launch_backward_planes(const UnprojArgs& a, int mm_unfused, hipStream_t stream, int tile) {
+  if (mm_unfused != 0 && mm_unfused != TEMPO_UNFUSED_ALL) return TEMPO_E_ARG;
+  if (tile != 0 && tile != kBrickCapSmall && tile != kBrickCapLarge) return TEMPO_E_ARG;
+  if (a.W > 16384 || a.H > 16384) return TEMPO_E_SIZE;  // 16-bit footprint boxes
+  const bool large = tile == kBrickCapLarge;
+#define TEMPO_PBRICK_CASE(LL)                                                           \
+  case LL:                                                                              \
+    if (large)                                                                          \
+      return mm_unfused ? launch_backward_brick<LL, 1, kBrickCapLarge, 1>(a, stream)    \
+                        : launch_backward_brick<LL, 0, kBrickCapLarge, 1>(a, stream);   \
+    return mm_unfused ? launch_backward_brick<LL, 1, kBrickCapSmall, 1>(a, stream)      \
+                      : launch_backward_brick<LL, 0, kBrickCapSmall, 1>(a, stream);
+  switch (a.CP / 4) {
+    TEMPO_PBRICK_CASE(4)
+    TEMPO_PBRICK_CASE(5)
+    TEMPO_PBRICK_CASE(6)
+    TEMPO_PBRICK_CASE(7)
+    TEMPO_PBRICK_CASE(8)
+    default: return TEMPO_E_PAD;
+  }
+#undef TEMPO_PBRICK_CASE
+}
+
+template <int L, int UNF>
+int launch_claims_one(const UnprojArgs& a, hipStream_t stream) {
+  UnprojArgs k = a;
+  fill_order_magic(k.order, k.magic, a.V, a.dim);
+  k.wave_vox = kWaveVox;
+  k.tile_vox = kTileWaves * kWaveVox;
+  k.tiles = (a.N + k.tile_vox - 1) / k.tile_vox;
+  const long long total = (long long)a.NB * k.tiles;
+  if (total > 0x7fffffffLL / 8) return TEMPO_E_DIM;
+  k.total = (int)total;
+  k.chunk = (k.total + 7) / 8;
+  hipLaunchKernelGGL((window_claim_kernel<L, UNF>), dim3(8 * k.chunk), dim3(kTileWaves * 64),
+                     (size_t)kTileWaves * wave_lds_bytes(L), stream, k);
+  return (int)hipGetLastError();
+}
+
+int launch_claims(const UnprojArgs& a, int mm_unfused, hipStream_t stream) {
+#define TEMPO_CLAIM_CASE(LL)                                                    \
+  case LL:                                                                      \
+    return mm_unfused ? launch_claims_one<LL, 1>(a, stream) : launch_claims_one<LL, 0>(a, stream);
+  switch (a.CP / 4) {
+    TEMPO_CLAIM_CASE(4)
+    TEMPO_CLAIM_CASE(5)
+    TEMPO_CLAIM_CASE(6)
+    TEMPO_CLAIM_CASE(7)
+    TEMPO_CLAIM_CASE(8)
+    default: return TEMPO_E_PAD;
+  }
+#undef TEMPO_CLAIM_CASE
 }
 
 template <int MODE>
@@ -2627,6 +2855,11 @@ struct Extra {
   unsigned long long* cmask = nullptr;  // forward: record / backward: read the clamp mask
   float* ghm = nullptr;                 // backward: gradient of the heatmaps (accumulated)
   int tile = 0;                         // window backward: texels per LDS tile (0 = default)
+  // trainable window planes: claims [xy, xz, yz] (written when `planes_in`, else read by the
+  // backward together with the planes' gradients)
+  int32_t* claim[3] = {nullptr, nullptr, nullptr};
+  const float* gplane[3] = {nullptr, nullptr, nullptr};
+  bool planes_in = false;               // window_impl: the planes are INPUTS (claim pass)
 };
 
 // Where the heatmaps are: `hm` = the repacked [F][V][H][W][CP] buffer (all kernels), or
@@ -2937,6 +3170,52 @@ int tempo_unproject_window_backward(const float* grad_cubes, const float* cam,
                      const_cast<float*>(grad_cubes), nullptr, nullptr, nullptr, NW, F, V, C, CP,
                      H, W, FX, FY, FZ, VX, VY, VZ, hm_w, hm_h, img_w, img_h, mm_unfused,
                      nullptr, 0, ex, stream);
+}
+
+int tempo_window_planes_claims(const float* hm, const float* cam, const int32_t* win_frame,
+                               const float* fx, const float* fy, const float* fz,
+                               const int32_t* tl, const int32_t* start, const int32_t* end,
+                               const uint8_t* live, const float* plane_xy,
+                               const float* plane_xz, const float* plane_yz, int32_t* claim_xy,
+                               int32_t* claim_xz, int32_t* claim_yz, int NW, int F, int V,
+                               int C, int CP, int H, int W, int FX, int FY, int FZ, int VX,
+                               int VY, int VZ, float hm_w, float hm_h, float img_w,
+                               float img_h, int mm_unfused, void* stream) {
+  if (!hm || !plane_xy || !plane_xz || !plane_yz || !claim_xy || !claim_xz || !claim_yz)
+    return TEMPO_E_NULL;
+  // a claim word is 2 * index + blocked: keep it well inside 31 bits
+  if (VX >= (1 << 23) || VY >= (1 << 23) || VZ >= (1 << 23)) return TEMPO_E_DIM;
+  Extra ex;
+  ex.planes_in = true;
+  ex.claim[0] = claim_xy; ex.claim[1] = claim_xz; ex.claim[2] = claim_yz;
+  return window_impl(hm, cam, win_frame, fx, fy, fz, tl, start, end, live, nullptr,
+                     const_cast<float*>(plane_xy), const_cast<float*>(plane_xz),
+                     const_cast<float*>(plane_yz), NW, F, V, C, CP, H, W, FX, FY, FZ, VX, VY,
+                     VZ, hm_w, hm_h, img_w, img_h, mm_unfused, nullptr, 0, ex, stream);
+}
+
+int tempo_unproject_window_planes_backward(
+    const float* grad_xy, const float* grad_xz, const float* grad_yz, const int32_t* claim_xy,
+    const int32_t* claim_xz, const int32_t* claim_yz, const float* cam,
+    const int32_t* win_frame, const float* fx, const float* fy, const float* fz,
+    const int32_t* tl, const int32_t* start, const int32_t* end, const uint8_t* live,
+    float* grad_hm, int NW, int F, int V, int C, int CP, int H, int W, int FX, int FY, int FZ,
+    int VX, int VY, int VZ, float hm_w, float hm_h, float img_w, float img_h, int mm_unfused,
+    int tile_texels, void* stream) {
+  if (!grad_xy || !grad_xz || !grad_yz || !claim_xy || !claim_xz || !claim_yz || !grad_hm)
+    return TEMPO_E_NULL;
+  if (tile_texels != 0 && tile_texels != kBrickCapSmall && tile_texels != kBrickCapLarge)
+    return TEMPO_E_ARG;
+  Extra ex;
+  ex.ghm = grad_hm;
+  ex.tile = tile_texels;
+  ex.gplane[0] = grad_xy; ex.gplane[1] = grad_xz; ex.gplane[2] = grad_yz;
+  ex.claim[0] = const_cast<int32_t*>(claim_xy);
+  ex.claim[1] = const_cast<int32_t*>(claim_xz);
+  ex.claim[2] = const_cast<int32_t*>(claim_yz);
+  return window_impl(grad_hm, cam, win_frame, fx, fy, fz, tl, start, end, live, nullptr,
+                     nullptr, nullptr, nullptr, NW, F, V, C, CP, H, W, FX, FY, FZ, VX, VY, VZ,
+                     hm_w, hm_h, img_w, img_h, mm_unfused, nullptr, 0, ex, stream);
 }
 
 int tempo_unrepack_nchw(const float* in, void* const* views, int V, int B, int C_total,
@@ -3374,10 +3653,39 @@ int window_impl(const Layout& lay, const float* cam, const int32_t* win_frame, c
   a.groups = groups; a.NG = num_groups;
   const int lrc = apply_layout(a, lay);
   if (lrc != TEMPO_OK) return lrc;
-  // the planes are max-accumulated: they start at +0.0, the smallest clamped value
   const size_t nc = (size_t)NW * C * sizeof(float);
   float* const pl[3] = {plane_xy, plane_xz, plane_yz};
   const size_t pln[3] = {nc * VX * VY, nc * VX * VZ, nc * VY * VZ};
+  if (ex.planes_in) {
+    // claim pass: the finished planes come in, the claims start at a large positive word
+    // (any real claim, 2 * index + blocked < 2^24, is smaller)
+    if (lay.hm == nullptr || groups != nullptr) return TEMPO_E_ARG;
+    for (int i = 0; i < 3; i++) {
+      if (pl[i] == nullptr || ex.claim[i] == nullptr) return TEMPO_E_NULL;
+      const hipError_t e = hipMemsetAsync(ex.claim[i], 0x7f, pln[i], (hipStream_t)stream);
+      if (e != hipSuccess) return (int)e;
+      a.claim[i] = ex.claim[i];
+    }
+    a.pl01 = reinterpret_cast<unsigned*>(plane_xy);
+    a.pl02 = reinterpret_cast<unsigned*>(plane_xz);
+    a.pl12 = reinterpret_cast<unsigned*>(plane_yz);
+    return launch_claims(a, mm_unfused, (hipStream_t)stream);
+  }
+  if (ex.gplane[0] != nullptr) {
+    // backward from the planes' gradients (claims filed by the pass above)
+    if (ex.ghm == nullptr) return TEMPO_E_NULL;
+    for (int i = 0; i < 3; i++) {
+      if (ex.gplane[i] == nullptr || ex.claim[i] == nullptr) return TEMPO_E_NULL;
+      a.gplane[i] = ex.gplane[i];
+      a.claim[i] = ex.claim[i];
+    }
+    a.ghm = ex.ghm;
+    const hipError_t e = hipMemsetAsync(ex.ghm, 0, (size_t)F * a.frame_stride * sizeof(float),
+                                        (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return launch_backward_planes(a, mm_unfused, (hipStream_t)stream, ex.tile);
+  }
+  // the planes are max-accumulated: they start at +0.0, the smallest clamped value
   for (int i = 0; i < 3; i++) {
     if (pl[i] == nullptr) continue;
     const hipError_t e = hipMemsetAsync(pl[i], 0, pln[i], (hipStream_t)stream);

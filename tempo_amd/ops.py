@@ -306,6 +306,91 @@ def unproject_window_backward(grad_cubes, cam, fine_axes, tl, start, end, clamp_
     return ghm
 
 
+def window_planes_claims(hm, cam, fine_axes, tl, start, end, sub_cube, channels, planes,
+                         heatmap_size, image_size, win_frame=None, live=None, mm_mode='auto'):
+    """For training through :func:`unproject_window_planes`: per entry of the three FINAL
+    ``planes`` (that call's outputs on the same inputs) the claim of the voxel ``torch.max``
+    sends the entry's gradient to -- int32 tensors in the planes' shapes, 2 * (index along
+    the reduced axis of the first voxel attaining the maximum) + 1 if the clamp blocks the
+    gradient there (``tempo_window_planes_claims``)."""
+    lib = _lib.load()
+    dev, (F_, V, H, W, CP), fa, NW, (VX, VY, VZ), C = _window_args(
+        hm, cam, fine_axes, tl, start, end, sub_cube, channels, win_frame, live)
+    shapes = [(NW, C, VX, VY), (NW, C, VX, VZ), (NW, C, VY, VZ)]
+    planes = list(planes)
+    if len(planes) != 3:
+        raise ValueError('planes: the xy, xz and yz planes')
+    for t, sh in zip(planes, shapes):
+        _need(t, torch.float32, 'planes', dev)
+        if tuple(t.shape) != sh:
+            raise ValueError(f'planes: expected {sh}, got {tuple(t.shape)}')
+    claims = [torch.empty(sh, dtype=torch.int32, device=dev) for sh in shapes]
+    with torch.cuda.device(dev):
+        rc = lib.tempo_window_planes_claims(
+            _ptr(hm), _ptr(cam), _ptr(win_frame), _ptr(fa[0]), _ptr(fa[1]), _ptr(fa[2]),
+            _ptr(tl), _ptr(start), _ptr(end), _ptr(live), _ptr(planes[0]), _ptr(planes[1]),
+            _ptr(planes[2]), _ptr(claims[0]), _ptr(claims[1]), _ptr(claims[2]), NW, F_, V, C,
+            CP, H, W, int(fa[0].numel()), int(fa[1].numel()), int(fa[2].numel()), VX, VY, VZ,
+            float(heatmap_size[0]), float(heatmap_size[1]), float(image_size[0]),
+            float(image_size[1]), numerics.abi_flag(mm_mode), _stream_ptr(dev))
+    _lib.check(rc, 'tempo_window_planes_claims')
+    return claims
+
+
+def unproject_window_planes_backward(grad_planes, claims, cam, fine_axes, tl, start, end,
+                                     hm_shape, heatmap_size, image_size, win_frame=None,
+                                     live=None, mm_mode='auto', tile_texels=0):
+    """Gradient of :func:`unproject_window_planes`'s three planes with respect to the
+    repacked heatmaps, routed through :func:`window_planes_claims`:
+    ``grad_planes`` (xy, xz, yz) -> ``[F,V,H,W,CP]``.  Neither the window volume nor its
+    gradient volume exists at any point."""
+    lib = _lib.load()
+    dev = grad_planes[0].device
+    F_, V, H, W, CP = (int(v) for v in hm_shape)
+    _need(cam, torch.float32, 'cam', dev)
+    fa = [_need(a, torch.float32, 'fine_axes', dev) for a in fine_axes]
+    NW, C, VX, VY = (int(v) for v in grad_planes[0].shape)
+    VZ = int(grad_planes[1].shape[3])
+    shapes = [(NW, C, VX, VY), (NW, C, VX, VZ), (NW, C, VY, VZ)]
+    if len(grad_planes) != 3 or len(claims) != 3:
+        raise ValueError('grad_planes and claims: one tensor per plane (xy, xz, yz)')
+    for g, c, sh in zip(grad_planes, claims, shapes):
+        _need(g, torch.float32, 'grad_planes', dev)
+        _need(c, torch.int32, 'claims', dev)
+        if tuple(g.shape) != sh or tuple(c.shape) != sh:
+            raise ValueError(f'grad_planes / claims: expected {sh}')
+    for name, t in (('tl', tl), ('start', start), ('end', end)):
+        _need(t, torch.int32, name, dev)
+        if tuple(t.shape) != (NW, 3):
+            raise ValueError(f'{name} must be [{NW},3]')
+    if tuple(cam.shape) != (F_, V, 32):
+        raise ValueError(f'cam must be [{F_},{V},32], got {tuple(cam.shape)}')
+    if win_frame is not None:
+        _need(win_frame, torch.int32, 'win_frame', dev)
+        if win_frame.numel() != NW:
+            raise ValueError('win_frame must have one entry per window')
+    elif NW != F_:
+        raise ValueError('without win_frame there must be one window per frame')
+    if live is not None:
+        _need(live, torch.uint8, 'live', dev)
+        if live.numel() != NW:
+            raise ValueError('live must have one entry per window')
+    if C > CP:
+        raise ValueError('hm_shape: fewer padded channels than the planes have channels')
+    ghm = torch.empty(F_, V, H, W, CP, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.tempo_unproject_window_planes_backward(
+            _ptr(grad_planes[0]), _ptr(grad_planes[1]), _ptr(grad_planes[2]), _ptr(claims[0]),
+            _ptr(claims[1]), _ptr(claims[2]), _ptr(cam), _ptr(win_frame), _ptr(fa[0]),
+            _ptr(fa[1]), _ptr(fa[2]), _ptr(tl), _ptr(start), _ptr(end), _ptr(live), _ptr(ghm),
+            NW, F_, V, C, CP, H, W, int(fa[0].numel()), int(fa[1].numel()), int(fa[2].numel()),
+            VX, VY, VZ, float(heatmap_size[0]), float(heatmap_size[1]), float(image_size[0]),
+            float(image_size[1]), numerics.abi_flag(mm_mode), int(tile_texels),
+            _stream_ptr(dev))
+    _lib.check(rc, 'tempo_unproject_window_planes_backward')
+    return ghm
+
+
 # channel-last maps of one chunk stay in the 256 MB Infinity Cache between the repack that
 # writes them and the gather that reads them; the volume goes out with streaming stores and
 # does not compete for it (measured at config 2: 8 / 12 / 16 / 32 frames per chunk

@@ -238,6 +238,76 @@ class _Unproject(torch.autograd.Function):
         return (None,) + tuple(g if n else None for g, n in zip(grads, need))
 
 
+class _UnprojectPlanes(torch.autograd.Function):
+    """Differentiable fused window planes: forward = the inference kernel (no volume) plus the
+    claim pass that records which voxel ``torch.max`` would route each plane entry's gradient
+    to; backward = the window backward kernel fed from the three plane gradients through
+    those claims.  What autograd does through ``project_layer.py:278-378`` followed by the
+    three ``torch.max`` of ``tempo_pose.py:172-176`` -- without the ``[B,C,X,Y,Z]`` volume
+    or its gradient volume (config 3's shape, 320 windows: 48 ms through the volume)."""
+
+    @staticmethod
+    def forward(ctx, meta, *feature_maps):
+        """``feature_maps``: T x V tensors ``[B,C,H,W]``, timestep-major (T = ``meta['T']``,
+        default 1); frames are numbered ``t * B + b``; ``meta['win_frame']`` maps windows to
+        frames (None: window i looks at frame i)."""
+        dev = feature_maps[0].device
+        B, C, H, W = feature_maps[0].shape
+        T = int(meta.get('T', 1))
+        V = len(feature_maps) // T
+        NW = meta['tl'].shape[0]
+        vx, vy, vz = meta['sub_cube']
+        planes = [torch.empty(NW, C, *sh, dtype=torch.float32, device=dev)
+                  for sh in ((vx, vy), (vx, vz), (vy, vz))]
+        ctx.meta, ctx.saved, ctx.fm_shape, ctx.TV = meta, [], (B, C, H, W), (T, V)
+        for c0, cs in _Slices(C).items:
+            if T == 1:
+                hm = ops.repack_nhwc(feature_maps, c0, cs)
+            else:
+                hm = torch.empty(T * B, V, H, W, ops.padded_channels(cs), dtype=torch.float32,
+                                 device=dev)
+                for t in range(T):
+                    ops.repack_nhwc(feature_maps[t * V:(t + 1) * V], c0, cs,
+                                    out=hm[t * B:(t + 1) * B])
+            args = (hm, meta['cam'], meta['fine_axes'], meta['tl'], meta['start'], meta['end'],
+                    meta['sub_cube'], cs)
+            kw = dict(win_frame=meta.get('win_frame'), live=meta['live'],
+                      mm_mode=meta['mm_mode'])
+            whole = cs == C
+            out = ops.unproject_window_planes(
+                *args, meta['heatmap_size'], meta['image_size'], want_cubes=False,
+                planes_out=planes if whole else None, **kw)
+            claims = ops.window_planes_claims(*args, out[1:], meta['heatmap_size'],
+                                              meta['image_size'], **kw)
+            if not whole:
+                for dst, src in zip(planes, out[1:]):
+                    dst[:, c0:c0 + cs] = src
+            ctx.saved.append((c0, cs, claims, tuple(hm.shape)))
+        return tuple(planes)
+
+    @staticmethod
+    def backward(ctx, g_xy, g_xz, g_yz):
+        _alert_not_deterministic()
+        meta = ctx.meta
+        B, C, H, W = ctx.fm_shape
+        T, V = ctx.TV
+        dev = g_xy.device
+        grads = [torch.zeros(B, C, H, W, dtype=torch.float32, device=dev)
+                 for _ in range(T * V)]
+        for c0, cs, claims, hm_shape in ctx.saved:
+            gp = [g[:, c0:c0 + cs].float().contiguous() for g in (g_xy, g_xz, g_yz)]
+            ghm = ops.unproject_window_planes_backward(
+                gp, claims, meta['cam'], meta['fine_axes'], meta['tl'], meta['start'],
+                meta['end'], hm_shape, meta['heatmap_size'], meta['image_size'],
+                win_frame=meta.get('win_frame'), live=meta['live'], mm_mode=meta['mm_mode'],
+                tile_texels=meta.get('tile_texels', 0))
+            for t in range(T):
+                ops.unrepack_nchw(ghm[t * B:(t + 1) * B], C, c0, cs,
+                                  out=grads[t * V:(t + 1) * V])
+        need = ctx.needs_input_grad[1:]
+        return (None,) + tuple(g if n else None for g, n in zip(grads, need))
+
+
 def _base_axis(size, bins):
     """``torch.linspace(-size/2, size/2, bins)`` exactly as compute_grid calls it
     (on the CPU: torch's CPU linspace is the oracle's arithmetic)."""
@@ -770,12 +840,26 @@ class ProjectLayerWithMask(nn.Module):
         cubes | None)``; with ``want_cubes=False`` the ``[B,C,X,Y,Z]`` volume is never
         written to memory."""
         if _wants_grad(feature_maps):
-            # training: the volume through the differentiable path and autograd's own
-            # torch.max (tempo_pose.py:172-176 as written); a planes-gradient backward was
-            # priced at 12 ms against this path's 19 and not built (DESIGN.md section 4)
-            cubes, offset = self.get_voxel(feature_maps, grid_center, centers, scales, cameras)
-            return (torch.max(cubes, dim=4)[0], torch.max(cubes, dim=3)[0],
-                    torch.max(cubes, dim=2)[0], offset, cubes if want_cubes else None)
+            if want_cubes:
+                # the caller wants the volume as well: the differentiable volume path and
+                # autograd's own torch.max (tempo_pose.py:172-176 as written)
+                cubes, offset = self.get_voxel(feature_maps, grid_center, centers, scales,
+                                               cameras)
+                return (torch.max(cubes, dim=4)[0], torch.max(cubes, dim=3)[0],
+                        torch.max(cubes, dim=2)[0], offset, cubes)
+            # training through the planes alone: no volume, no gradient volume
+            device, B, C, offset, live, cam, (tl, st, en) = self._window_inputs(
+                feature_maps, grid_center, centers, scales, cameras)
+            tile = int(getattr(self, 'backward_tile', 0) or 0)
+            if tile == 0 and not self._cam_host.is_cuda:
+                tile = ops.backward_tile_texels(self._cam_host, self._fine_axes_host,
+                                                self.heatmap_size, self.image_size)
+            meta = dict(cam=cam, fine_axes=self._fine_axes, tl=tl, start=st, end=en,
+                        sub_cube=list(self._sub_cube), live=live,
+                        heatmap_size=self.heatmap_size, image_size=self.image_size,
+                        mm_mode=self.mm_mode, tile_texels=tile)
+            pxy, pxz, pyz = _UnprojectPlanes.apply(meta, *[fm.float() for fm in feature_maps])
+            return pxy, pxz, pyz, offset, None
         device, B, C, offset, live, cam, (tl, st, en) = self._window_inputs(
             feature_maps, grid_center, centers, scales, cameras)
         vx, vy, vz = self._sub_cube
@@ -821,9 +905,41 @@ class ProjectLayerWithMask(nn.Module):
         T = len(feature_maps_t)
         device = _check_inputs(feature_maps_t[0])
         self.set_space_size(space_center, space_size, sub_space_size, sub_cube_size, device)
+        if any(_wants_grad(f) for f in feature_maps_t) and not want_cubes:
+            # training through the planes: all B * P * T windows in one differentiable call
+            # (one repack per timestep, one claim pass, one backward whose atomics also do
+            # the summing over proposals that autograd would do tensor by tensor)
+            B, C = feature_maps_t[0][0].shape[:2]
+            V = len(feature_maps_t[0])
+            P = candidates.shape[1]
+            cand = candidates.to(device).reshape(B * P, -1)
+            centers_tl, offset, start, end = self.window_geometry(cand)
+            self._ensure_grids(device)
+            live = None
+            if cand.shape[1] != 3:
+                live = (cand[:, 3] >= 0).to(torch.uint8).repeat_interleave(T).contiguous()
+            rep = lambda x: x.to(torch.int32).repeat_interleave(T, 0).contiguous()
+            i = torch.arange(B * P * T, device=device)
+            win_frame = ((i % T) * B + i // (P * T)).to(torch.int32).contiguous()
+            cam_host = torch.cat([pack_cameras(centers_t[t], scales_t[t], cameras_t[t],
+                                               self.image_size, self.mm_mode)
+                                  for t in range(T)], 0)
+            tile = int(getattr(self, 'backward_tile', 0) or 0)
+            if tile == 0 and not cam_host.is_cuda:
+                tile = ops.backward_tile_texels(cam_host, self._fine_axes_host,
+                                                self.heatmap_size, self.image_size)
+            meta = dict(cam=cam_host.to(device), fine_axes=self._fine_axes, tl=rep(centers_tl),
+                        start=rep(start), end=rep(end), sub_cube=list(self._sub_cube),
+                        live=live, win_frame=win_frame, T=T, heatmap_size=self.heatmap_size,
+                        image_size=self.image_size, mm_mode=self.mm_mode, tile_texels=tile)
+            flat = [fm.float() for fm_t in feature_maps_t for fm in fm_t]
+            planes = _UnprojectPlanes.apply(meta, *flat)
+            shape = lambda x: x.view(B, P, T, *x.shape[1:])
+            return (shape(planes[0]), shape(planes[1]), shape(planes[2]),
+                    offset.view(B, P, 3), None)
         if any(_wants_grad(f) for f in feature_maps_t):
-            # training: the caller's two loops as written (tempo_pose.py:145-156, :266), each
-            # call through the differentiable path
+            # training with the volume asked for: the caller's two loops as written
+            # (tempo_pose.py:145-156, :266), each call through the differentiable volume path
             P_ = candidates.shape[1]
             rows = [[self.get_planes(feature_maps_t[t], candidates[:, n].to(device),
                                      centers_t[t], scales_t[t], cameras_t[t],

@@ -110,6 +110,32 @@ def test_new_entry_points_reject_bad_arguments():
         512.0, 0, kw.get('tile', 0), None)
     assert wbwd(ghm=None) == -1 and wbwd(NW=8) == -5
     assert wbwd(tile=100) == -5 and wbwd(tile=-1) == -5  # 0 (default), 121 or 144
+    # training through the planes: all six plane / claim pointers, the tile, the usual limits
+    def claims(**kw):
+        a = dict(hm=one, xy=one, xz=one, yz=one, cxy=one, cxz=one, cyz=one, NW=4, CP=16, VZ=64,
+                 mm=0)
+        a.update(kw)
+        return lib.tempo_window_planes_claims(
+            a['hm'], one, None, one, one, one, one, one, one, None, a['xy'], a['xz'], a['yz'],
+            a['cxy'], a['cxz'], a['cyz'], a['NW'], 4, 5, 15, a['CP'], 128, 240, 253, 253, 64, 64,
+            64, a['VZ'], 240.0, 128.0, 960.0, 512.0, a['mm'], None)
+    for k in ('hm', 'xy', 'xz', 'yz', 'cxy', 'cxz', 'cyz'):
+        assert claims(**{k: None}) == -1, k
+    assert claims(NW=0) == -2 and claims(NW=8) == -5 and claims(CP=18) == -3
+    assert claims(mm=3) == -5 and claims(VZ=1 << 23) == -2 and claims(hm=P(20)) == -5
+
+    def pbwd(**kw):
+        a = dict(gxy=one, gxz=one, gyz=one, cxy=one, cxz=one, cyz=one, ghm=one, NW=4, tile=0,
+                 W=240, mm=0)
+        a.update(kw)
+        return lib.tempo_unproject_window_planes_backward(
+            a['gxy'], a['gxz'], a['gyz'], a['cxy'], a['cxz'], a['cyz'], one, None, one, one, one,
+            one, one, one, None, a['ghm'], a['NW'], 4, 5, 15, 16, 128, a['W'], 253, 253, 64, 64,
+            64, 64, 240.0, 128.0, 960.0, 512.0, a['mm'], a['tile'], None)
+    for k in ('gxy', 'gxz', 'gyz', 'cxy', 'cxz', 'cyz', 'ghm'):
+        assert pbwd(**{k: None}) == -1, k
+    assert pbwd(tile=100) == -5 and pbwd(NW=8) == -5 and pbwd(mm=1) == -5
+    assert pbwd(ghm=P(20)) == -5 and pbwd(NW=0) == -2
     assert lib.tempo_clamp_mask_words(128000, 16) == 2000 * 16
     assert lib.tempo_clamp_mask_words(65, 20) == 2 * 24
     assert lib.tempo_clamp_mask_words(0, 16) == -2 and lib.tempo_clamp_mask_words(64, 18) == -3
