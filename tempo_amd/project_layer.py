@@ -838,7 +838,9 @@ class ProjectLayerWithMask(nn.Module):
         unprojection kernel.  Call ``set_space_size`` first (as ``forward`` does).
         Returns ``(plane_xy [B,C,X,Y], plane_xz [B,C,X,Z], plane_yz [B,C,Y,Z], offset,
         cubes | None)``; with ``want_cubes=False`` the ``[B,C,X,Y,Z]`` volume is never
-        written to memory."""
+        written to memory -- in training either: when a feature map requires a gradient the
+        planes come from :class:`_UnprojectPlanes`, whose backward sends the planes'
+        gradients to the heatmaps without a volume or a gradient volume."""
         if _wants_grad(feature_maps):
             if want_cubes:
                 # the caller wants the volume as well: the differentiable volume path and
