@@ -2,7 +2,8 @@
 ``@force_fp32(apply_to=('feature_maps', 'centers'))`` (project_layer.py:65, :242): under
 mixed-precision training the 2-D head hands over fp16 / bf16 maps and the layer samples their
 fp32 conversion.  The drop-in does the same: the result must equal the module fed the
-converted maps bit for bit, forward and backward."""
+converted maps bit for bit in the forward, and to one rounding step of the maps' dtype in the
+backward (its atomics have no fixed order)."""
 import pytest
 import torch
 
@@ -52,7 +53,10 @@ def test_window_half_maps_forward_and_backward(dtype, gpu_device):
     for h, f in zip(half, full):
         # autograd casts the fp32 gradient of `.float()` back to the map's dtype
         assert h.grad is not None and h.grad.dtype == dtype
-        assert torch.equal(h.grad, f.grad.to(dtype))
+        # (two backward runs: the fp32 atomics' order is not fixed, so equal up to the last
+        # fp32 bits before the cast -- one rounding step of the 16-bit type at most)
+        rtol = 1e-3 if dtype == torch.float16 else 8e-3
+        assert torch.allclose(h.grad.float(), f.grad, rtol=rtol, atol=1e-6)
     assert any(float(f.grad.abs().max()) > 0 for f in full)
 
 
