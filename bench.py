@@ -1060,6 +1060,58 @@ def main():
                  'backward_tile_texels': tile}
         del gout, grads, ghm, cmask
 
+    # training step THROUGH the fused planes (--planes only --backward): planes + claim pass,
+    # backward from the planes' gradients; no volume, no gradient volume
+    if (rank == 0 and args.backward and args.planes == 'only' and
+            args.workload.startswith('window') and not wl.nhwc):
+        ops = wl.ops
+        if wl.hm.shape[0] != wl.B:
+            wl.hm = torch.empty(wl.B, *wl.hm.shape[1:], device=dev)
+            wl.chunk = wl.B
+        ops.repack_nhwc(wl.fms, out=wl.hm)
+        tl, st, en = wl.geo
+        hs, im = wl.cfg['heatmap_size'], wl.cfg['image_size']
+        tile = ops.backward_tile_texels(wl.cam_host, wl.fine_host, hs, im)
+        gpl = [torch.rand(p.shape, device=dev) for p in wl.planes]
+        grads = [torch.zeros_like(f) for f in wl.fms]
+        state = {}
+
+        def pfwd():
+            ops.unproject_window_planes(wl.hm, wl.cam, wl.fine, tl, st, en, wl.sub, wl.J, hs, im,
+                                        win_frame=wl.win_frame, planes_out=wl.planes)
+
+        def pclaims():
+            state['claims'] = ops.window_planes_claims(wl.hm, wl.cam, wl.fine, tl, st, en, wl.sub,
+                                                       wl.J, wl.planes, hs, im,
+                                                       win_frame=wl.win_frame)
+
+        def pbwd():
+            return ops.unproject_window_planes_backward(
+                gpl, state['claims'], wl.cam, wl.fine, tl, st, en, wl.hm.shape, hs, im,
+                win_frame=wl.win_frame, tile_texels=tile)
+
+        def ptimed(fn, n=10):
+            for _ in range(2):
+                r = fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                r = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n, r
+
+        f_ms, _ = ptimed(pfwd)
+        c_ms, _ = ptimed(pclaims)
+        b_ms, ghm = ptimed(pbwd)
+        u_ms, _ = ptimed(lambda: ops.unrepack_nchw(ghm, wl.J, out=grads))
+        train = {'through': 'fused planes (no volume, no gradient volume)',
+                 'planes_forward_ms': round(f_ms, 4), 'claim_pass_ms': round(c_ms, 4),
+                 'backward_ms': round(b_ms, 4), 'unrepack_ms': round(u_ms, 4),
+                 'backward_gsamp_s': round(wl.samples / (b_ms * 1e-3) / 1e9, 3),
+                 'backward_tile_texels': tile}
+        del gpl, grads, ghm, state
+
     if rank == 0:
         traffic, traffic_src = measured_traffic(args, wl)
         ms_step = elapsed / args.steps * 1e3
