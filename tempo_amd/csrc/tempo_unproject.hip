@@ -1791,7 +1791,7 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
   // the forward's clamp blocks it, parked as [channel][voxel]
   float x = 0.f, y = 0.f, z = 0.f;
   bool have = false;
-  bool hot = true;  // PLN: this lane's voxel holds a gradient in some channel
+  bool hot = true;  // this lane's voxel holds a gradient in some channel
   if (PLN) {
     const float den = (float)a.V + 1e-6f;
     const int d0 = a.dim[0], d1 = a.dim[1], d2 = a.dim[2];
@@ -1861,12 +1861,20 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
     have = inb && voxel_world<MODE>(a, b, n, &x, &y, &z);
     if (__builtin_amdgcn_ballot_w64(have) == 0) return;
     __builtin_amdgcn_sched_barrier(0);
+    // (a voxel whose gradient is zero in every channel -- blocked by the clamp, or simply
+    // zero: what torch.max's backward leaves in two thirds of a volume -- adds nothing and
+    // stays out of the footprint box below)
+    bool any = false;
 #pragma unroll
     for (int ch = 0; ch < CP; ch++) {
       const int cq = ch >> 2, j = ch & 3;
       const bool open = inb && ch < a.C && ((word[j] >> (vq * L + cq)) & 1ull);
-      st[ch * TSTR + lane] = open ? gv[ch] / den : 0.0f;
+      const float g = open ? gv[ch] / den : 0.0f;
+      st[ch * TSTR + lane] = g;
+      any = any || g != 0.0f;
     }
+    if (__builtin_amdgcn_ballot_w64(any) == 0) return;
+    hot = any;
   }
 
   // step layout: TP footprint texels x CP channels per instruction
@@ -1894,8 +1902,8 @@ __global__ __launch_bounds__(64) void window_backward_brick_kernel(const UnprojA
     const bool ok = have && gx == gx && gy == gy;
     const bool cx[2] = {ok && (unsigned)x0 < (unsigned)a.W, ok && (unsigned)(x0 + 1) < (unsigned)a.W};
     const bool ry[2] = {(unsigned)y0 < (unsigned)a.H, (unsigned)(y0 + 1) < (unsigned)a.H};
-    // (PLN: two thirds of a brick's voxels hold no gradient; left out, the footprint box is
-    // the hot voxels' alone: fewer bricks that need halves, shorter flushes)
+    // (fed from the planes, two thirds of a brick's voxels hold no gradient; left out, the
+    // footprint box is the hot voxels' alone: fewer bricks that need halves, shorter flushes)
     const bool on = hot && (cx[0] || cx[1]) && (ry[0] || ry[1]);
     const unsigned inmap = (cx[0] && ry[0] ? 1u : 0u) | (cx[1] && ry[0] ? 2u : 0u) |
                            (cx[0] && ry[1] ? 4u : 0u) | (cx[1] && ry[1] ? 8u : 0u);
