@@ -75,6 +75,9 @@ def parse(argv=None):
     ap.add_argument('--backward', action='store_true',
                     help='also time the training step (forward with clamp mask + backward + '
                          'un-repack) and report it beside the headline')
+    ap.add_argument('--tile', type=int, default=None,
+                    help='window backward: texels per LDS tile (default: chosen from the lattice '
+                         'pitch like the drop-in module does)')
     ap.add_argument('--chunk', type=int, default=None,
                     help='root workload: frames per repack+unproject chunk (one reused '
                          'channel-last buffer that stays in the Infinity Cache)')
@@ -1071,7 +1074,8 @@ def main():
         ops.repack_nhwc(wl.fms, out=wl.hm)
         tl, st, en = wl.geo
         hs, im = wl.cfg['heatmap_size'], wl.cfg['image_size']
-        tile = ops.backward_tile_texels(wl.cam_host, wl.fine_host, hs, im)
+        tile = args.tile if args.tile is not None else ops.backward_tile_texels(
+            wl.cam_host, wl.fine_host, hs, im, planes=True)
         gpl = [torch.rand(p.shape, device=dev) for p in wl.planes]
         grads = [torch.zeros_like(f) for f in wl.fms]
         state = {}

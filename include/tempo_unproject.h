@@ -432,7 +432,9 @@ int tempo_unproject_window_backward(const float* grad_cubes, const float* cam,
  * tempo_unproject_window_planes_backward: grad_xy / grad_xz / grad_yz (the planes'
  *   incoming gradients, fp32, planes' layouts) + those claims -> grad_hm [F, V, H, W, CP]
  *   (zeroed, then accumulated with fp32 atomics like tempo_unproject_window_backward, whose
- *   kernel it shares; tile_texels as there).  Maps wider or taller than 16384 texels:
+ *   kernel it shares; tile_texels 0 (= 81), 81, 121 or 144: the footprint boxes here are
+ *   those of a brick's claimed voxels alone, so the small tile is the fast one).  Maps wider
+ *   or taller than 16384 texels:
  *   TEMPO_E_SIZE.  Follow with tempo_unrepack_nchw for per-view NCHW gradients. */
 int tempo_window_planes_claims(const float* hm, const float* cam,
                                const int32_t* win_frame, const float* fx,

@@ -253,12 +253,16 @@ def unproject_root_backward(grad_cubes, cam, axes, clamp_mask, hm_shape, heatmap
 BACKWARD_TILE_PITCH = 2.2  # heatmap pixels per voxel from which the 144-texel tile pays
 
 
-def backward_tile_texels(cam_host, fine_axes_host, heatmap_size, image_size):
-    """Tile size for :func:`unproject_window_backward` from the lattice's pitch in heatmap
+def backward_tile_texels(cam_host, fine_axes_host, heatmap_size, image_size, planes=False):
+    """Tile size for :func:`unproject_window_backward` (``planes``: for
+    :func:`unproject_window_planes_backward`, see the end) from the lattice's pitch in heatmap
     pixels: voxel pitch x focal length x affine scale x heatmap / image width, over the
     cameras' distance to the middle of the lattice (host arithmetic on the packed camera
     table, no device sync).  121 texels up to ``BACKWARD_TILE_PITCH`` pixels per voxel (config
-    3: 1.5), 144 beyond (H36M windows on 384 x 384 maps: 2.8; 5.00 -> 4.67 ms)."""
+    3: 1.5), 144 beyond (H36M windows on 384 x 384 maps: 2.8; 5.00 -> 4.67 ms).  The planes'
+    backward boxes only a brick's hot voxels, a third of them, and wants the small tile at
+    either pitch (ms per launch at 81 / 121 / 144 texels: config 3 10.9 / 13.5 / 15.9, the
+    H36M slice 8.6 / 10.8 / 11.2): 81."""
     cam = cam_host.reshape(-1, 32)[:64].double()
     ax = [a.double() for a in fine_axes_host]
     mid = torch.stack([a[a.numel() // 2] for a in ax])
@@ -266,6 +270,8 @@ def backward_tile_texels(cam_host, fine_axes_host, heatmap_size, image_size):
     depth = (mid[None, :] @ cam[:, 0:9].reshape(-1, 3, 3))[:, 0, 2] + cam[:, 11]
     px = pitch_mm * cam[:, 12].abs() * cam[:, 24].abs() * (heatmap_size[0] / image_size[0]) \
         / depth.abs().clamp_min(1.0)
+    if planes:
+        return 81
     return 144 if float(px.median()) >= BACKWARD_TILE_PITCH else 121
 
 

@@ -855,7 +855,7 @@ class ProjectLayerWithMask(nn.Module):
             tile = int(getattr(self, 'backward_tile', 0) or 0)
             if tile == 0 and not self._cam_host.is_cuda:
                 tile = ops.backward_tile_texels(self._cam_host, self._fine_axes_host,
-                                                self.heatmap_size, self.image_size)
+                                                self.heatmap_size, self.image_size, planes=True)
             meta = dict(cam=cam, fine_axes=self._fine_axes, tl=tl, start=st, end=en,
                         sub_cube=list(self._sub_cube), live=live,
                         heatmap_size=self.heatmap_size, image_size=self.image_size,
@@ -929,7 +929,7 @@ class ProjectLayerWithMask(nn.Module):
             tile = int(getattr(self, 'backward_tile', 0) or 0)
             if tile == 0 and not cam_host.is_cuda:
                 tile = ops.backward_tile_texels(cam_host, self._fine_axes_host,
-                                                self.heatmap_size, self.image_size)
+                                                self.heatmap_size, self.image_size, planes=True)
             meta = dict(cam=cam_host.to(device), fine_axes=self._fine_axes, tl=rep(centers_tl),
                         start=rep(start), end=rep(end), sub_cube=list(self._sub_cube),
                         live=live, win_frame=win_frame, T=T, heatmap_size=self.heatmap_size,

@@ -134,7 +134,8 @@ def test_new_entry_points_reject_bad_arguments():
             64, 64, 240.0, 128.0, 960.0, 512.0, a['mm'], a['tile'], None)
     for k in ('gxy', 'gxz', 'gyz', 'cxy', 'cxz', 'cyz', 'ghm'):
         assert pbwd(**{k: None}) == -1, k
-    assert pbwd(tile=100) == -5 and pbwd(NW=8) == -5 and pbwd(mm=1) == -5
+    assert pbwd(tile=100) == -5 and pbwd(tile=64) == -5  # 0 (= 81), 81, 121 or 144
+    assert pbwd(NW=8) == -5 and pbwd(mm=1) == -5
     assert pbwd(ghm=P(20)) == -5 and pbwd(NW=0) == -2
     assert lib.tempo_clamp_mask_words(128000, 16) == 2000 * 16
     assert lib.tempo_clamp_mask_words(65, 20) == 2 * 24

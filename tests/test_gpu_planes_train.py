@@ -27,9 +27,10 @@ def _oracle(case, maps, weights):
         [f.grad for f in leafs]
 
 
-def _run(case, maps, weights, dev):
+def _run(case, maps, weights, dev, tile=0):
     import tempo_amd
     layer = tempo_amd.ProjectLayerWithMask(case['image_size'], case['heatmap_size'], 'mean')
+    layer.backward_tile = tile  # 0: the module's own choice
     args = case['args']
     layer.set_space_size(*args[2:6], dev)
     leafs = [m.clone().to(dev).requires_grad_(True) for m in maps]
@@ -46,7 +47,7 @@ def _run(case, maps, weights, dev):
     return [p.detach() for p in (pxy, pxz, pyz)], inf, [f.grad for f in leafs], peak, layer
 
 
-def _check(name, case, maps, dev, peak_limit=None):
+def _check(name, case, maps, dev, peak_limit=None, tile=0):
     g = torch.Generator().manual_seed(17)
     B, C = maps[0].shape[0], maps[0].shape[1]
     NW = case['args'][1].shape[0]
@@ -54,7 +55,7 @@ def _check(name, case, maps, dev, peak_limit=None):
     weights = [torch.randn(NW, C, *sh, generator=g)
                for sh in ((v[0], v[1]), (v[0], v[2]), (v[1], v[2]))]
     cubes, ref_planes, ref_arg, ref_grads = _oracle(case, maps, weights)
-    planes, inf, grads, peak, layer = _run(case, maps, weights, dev)
+    planes, inf, grads, peak, layer = _run(case, maps, weights, dev, tile)
     for p, q, r in zip(planes, inf, ref_planes):
         # the training forward is the inference kernel; both equal torch.max of the oracle
         assert torch.equal(torch.nan_to_num(p, nan=-7.0), torch.nan_to_num(q, nan=-7.0))
@@ -73,10 +74,13 @@ def _check(name, case, maps, dev, peak_limit=None):
     return cubes, ref_arg, layer
 
 
+@pytest.mark.parametrize('tile', [0, 81, 121, 144])
 @pytest.mark.parametrize('name', list(cases.WINDOW_CASES))
-def test_planes_gradient_named_cases(name, gpu_device):
+def test_planes_gradient_named_cases(name, tile, gpu_device):
+    """(every LDS tile size of the backward: boxes that fit, bricks done as halves, and the
+    per-sample path for what still does not fit)"""
     case = cases.build_window(name)
-    _check(name, case, case['args'][0], gpu_device)
+    _check(f'{name} tile {tile}', case, case['args'][0], gpu_device, tile=tile)
 
 
 @pytest.mark.parametrize('hm', ['blobs', 'noise'])
