@@ -1018,6 +1018,16 @@ __global__ __launch_bounds__(kTileWaves * 64) void window_claim_kernel(const Unp
   // heatmaps (mostly zero) that is nearly every line.  Other ties are rare; their claims
   // simply race to the minimum.  No claim is read back here: fire-and-forget atomics.
   auto file = [&](int32_t* claim, int word) { atomicMin(claim, word); };
+  // (a z-column wave: the xy claims of its channels are minima over the wave's own lanes,
+  // collected with LDS atomics in the tile's padding column -- word 64 of every channel row,
+  // which nobody reads -- and stored by one instruction at the end; as 15 DPP wave reductions
+  // and 15 single-lane stores they were a third of the epilogue's 680 VALU instructions)
+  unsigned* pad = reinterpret_cast<unsigned*>(wbase) + kWaveVox;  // + ch * TSTR
+  if (column) {
+    if (lane < 4 * L) pad[lane * TSTR] = 0xffffffffu;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
 #pragma unroll 1
   for (int c0 = 0; c0 < a.C; c0 += G) {
     unsigned m01[G], m02[G], m12[G];
@@ -1042,17 +1052,24 @@ __global__ __launch_bounds__(kTileWaves * 64) void window_claim_kernel(const Unp
         return mine && (v == m || (isnan && m != m)) && (m != 0.0f || index == 0);
       };
       const bool h01 = hit(m01[g], i2);
-      if (column) {
-        // the wave IS the line: the minimum over its lanes is the claim, stored plainly
-        // (unsigned maximum of the complement = minimum; lanes without a claim offer 0)
-        const unsigned w = h01 ? ~(unsigned)((i2 << 1) | blocked) : 0u;
-        const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)wave_umax_to_lane63(w), 63);
-        if (m != 0u && lane == 0) k01[(long long)ch * s01 + o01] = (int)~m;
-      } else if (h01) {
-        file(k01 + (long long)ch * s01 + o01, (i2 << 1) | blocked);
+      if (h01) {
+        if (column)  // the wave IS the line
+          __hip_atomic_fetch_min(pad + ch * TSTR, (unsigned)((i2 << 1) | blocked),
+                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else
+          file(k01 + (long long)ch * s01 + o01, (i2 << 1) | blocked);
       }
       if (hit(m02[g], i1)) file(k02 + (long long)ch * s02 + o02, (i1 << 1) | blocked);
       if (hit(m12[g], i0)) file(k12 + (long long)ch * s12 + o12, (i0 << 1) | blocked);
+    }
+  }
+  if (column) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < a.C) {
+      const unsigned w = pad[lane * TSTR];
+      const int e = __builtin_amdgcn_readfirstlane(o01);  // (every lane of the wave is a voxel)
+      if (w != 0xffffffffu) k01[(long long)lane * s01 + e] = (int)w;
     }
   }
 }

@@ -9,7 +9,8 @@ from collections import defaultdict
 
 
 def short(name):
-    for key in ('unproject_columns_kernel', 'assemble_zslabs_kernel', 'conv1x1_nhwc_kernel',
+    for key in ('window_claim_kernel', 'unproject_columns_kernel', 'assemble_zslabs_kernel',
+                'conv1x1_nhwc_kernel',
                 'window_brick_kernel', 'gather_kernel', 'footprint_kernel', 'zcolumns_kernel',
                 'window_backward_brick_kernel', 'unproject_backward_kernel', 'unrepack_kernel',
                 'unproject_planes_kernel', 'unproject_group_kernel', 'unproject_kernel',
