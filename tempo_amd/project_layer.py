@@ -340,6 +340,7 @@ class ProjectLayer(nn.Module):
         self.keep_zmax = False
         self.last_zmax = None
         self._axes_cache = {}
+        self._train_volume = None  # see _training_volume
         # batch items with bit-identical camera records and grid centre (frames of
         # one recording) share one projection per voxel; results do not change
         # (opt-in: on MI355X the root kernel is bound by the texel gather, not by the
@@ -535,6 +536,30 @@ class ProjectLayer(nn.Module):
                         device)
         return device, B, C, live, axes, cube_size, cam
 
+    def _training_volume(self, feature_maps, grid_size, grid_center, cube_size, centers, scales,
+                         cameras):
+        """The differentiable volume for :meth:`forward_zmax` / :meth:`zcolumns` under
+        autograd.  The detector calls them one after the other on the same inputs (z-max ->
+        CenterNet -> top-K cells -> z-columns, ``tempo_detector.py:193-206``): the second call
+        reuses the first one's volume -- same tensor objects at the same versions, same
+        geometry, same packed camera table -- instead of unprojecting (and later
+        back-propagating) twice.  One volume is kept alive until the next call."""
+        table = pack_cameras(centers, scales, cameras, self.image_size, self.mm_mode)
+        key = (tuple((id(fm), fm._version) for fm in feature_maps), id(table), repr(grid_size),
+               repr([list(map(float, c)) for c in grid_center]) if not isinstance(
+                   grid_center, torch.Tensor) else (id(grid_center), grid_center._version),
+               repr(cube_size), self.mm_mode if isinstance(self.mm_mode, str) else
+               repr(self.mm_mode))
+        hit = getattr(self, '_train_volume', None)
+        if hit is not None and hit[0] == key and hit[1] is table and all(
+                a is b for a, b in zip(hit[2], feature_maps)):
+            return hit[3]
+        cubes, _ = self.get_voxel(feature_maps, grid_size, grid_center, cube_size, centers,
+                                  scales, cameras)
+        # (the tensors are kept with the key: an id can only be reused once its owner is gone)
+        self._train_volume = (key, table, list(feature_maps), cubes)
+        return cubes
+
     def forward_zmax(self, feature_maps, grid_size, grid_center, cube_size, centers, scales,
                      cameras):
         """Extension: ``torch.max(forward(...)[0], dim=4)[0]`` -- the first
@@ -545,9 +570,10 @@ class ProjectLayer(nn.Module):
         map requires a gradient the call goes through :meth:`forward` and ``torch.max``
         (differentiable, unfused)."""
         if _wants_grad(feature_maps):  # training: the volume and autograd's own torch.max
-            cubes, _ = self.get_voxel(feature_maps, grid_size, grid_center, cube_size, centers,
-                                      scales, cameras)
+            cubes = self._training_volume(feature_maps, grid_size, grid_center, cube_size,
+                                          centers, scales, cameras)
             return torch.max(cubes, dim=4)[0]
+        self._train_volume = None
         device, B, C, live, axes, cube_size, cam = self._consumer_inputs(
             feature_maps, grid_size, grid_center, cube_size, centers, scales, cameras,
             'forward_zmax')
@@ -579,8 +605,8 @@ class ProjectLayer(nn.Module):
         computed from the heatmaps (only those K * Z voxels are unprojected): bit-identical
         to gathering from :meth:`forward`'s volume, which need not exist."""
         if _wants_grad(feature_maps):  # training: the detector's own expression on the volume
-            cubes, _ = self.get_voxel(feature_maps, grid_size, grid_center, cube_size, centers,
-                                      scales, cameras)
+            cubes = self._training_volume(feature_maps, grid_size, grid_center, cube_size,
+                                          centers, scales, cameras)
             B_, C_, Z_ = cubes.shape[0], cubes.shape[1], cubes.shape[4]
             idx = index.to(device=cubes.device, dtype=torch.int64).view(B_, -1, 1, 1)
             return torch.gather(torch.flatten(cubes, 2, 3).permute(0, 2, 1, 3), dim=1,

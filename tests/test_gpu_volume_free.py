@@ -169,9 +169,24 @@ def test_fused_consumers_under_autograd(gpu_device):
     dcase = cases.to_device(case, gpu_device)
     layer = tempo_amd.ProjectLayer(case['image_size'], case['heatmap_size'], 'mean')
     fms = [f.clone().requires_grad_(True) for f in dcase['args'][0]]
+    calls = []
+    plain_get_voxel = layer.get_voxel
+    layer.get_voxel = lambda *a, **k: (calls.append(1), plain_get_voxel(*a, **k))[1]
     zmax = layer.forward_zmax(fms, *dcase['args'][1:])
     cols = layer.zcolumns(fms, *dcase['args'][1:], index.to(gpu_device))
     assert zmax.requires_grad and cols.requires_grad
+    # the detector's two calls on the same inputs share ONE differentiable volume
+    assert len(calls) == 1
+    other = [f.clone().requires_grad_(True) for f in dcase['args'][0]]
+    layer.zcolumns(other, *dcase['args'][1:], index.to(gpu_device))  # other tensors: no reuse
+    assert len(calls) == 2
+    layer.zcolumns(other, *dcase['args'][1:], index.to(gpu_device))  # unchanged: reused
+    assert len(calls) == 2
+    with torch.no_grad():
+        other[0].add_(0.0)  # edited in place since (its version moved): no reuse
+    layer.zcolumns(other, *dcase['args'][1:], index.to(gpu_device))
+    assert len(calls) == 3
+    layer.get_voxel = plain_get_voxel
     ((zmax * wz.to(gpu_device)).sum() + (cols * wc.to(gpu_device)).sum()).backward()
     for a, b in zip(fms, ref_fms):
         assert float((a.grad.cpu() - b.grad).abs().max()) <= 2e-5 * max(1.0, float(b.grad.abs().max()))
